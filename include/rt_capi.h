@@ -1,0 +1,140 @@
+/* rt_capi.h -- the C-ABI of libraytracer_amd.so: plain pointers and sizes, no C++ or torch types.
+ *
+ * The reference has no FFI layer: its hot path sits behind three free C++ functions and two globals
+ * (/root/reference/src/raytracer.h:12-18).  This header is what a binding of that API onto the MI355X path
+ * calls.  Every entry point names the reference interface it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative RT_E* code on failure; rt_last_error() gives the
+ *     text (thread-local).  Nothing calls exit() (the reference does, raytracer.cpp:127-130).
+ *   - "_dev" pointers are DEVICE (HBM) addresses on the scene's GPU; all others are host addresses.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); work is enqueued on it and the
+ *     call returns after it has completed unless the function says otherwise.
+ *   - vec3 arrays are tightly packed xyz floats (layout-compatible with glm::vec3[], raytracer.h:9-10).
+ *   - one rt_scene per (scene, device); calls on DIFFERENT handles may run concurrently, calls on one handle
+ *     must not (the handle owns its queues).
+ */
+#ifndef RT_CAPI_H
+#define RT_CAPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "rt_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK            0
+#define RT_EINVAL       -1   /* bad argument */
+#define RT_EIO          -2   /* file missing / unreadable  (reference: exit(EXIT_FAILURE), raytracer.cpp:127-130) */
+#define RT_EPARSE       -3   /* malformed scene            (reference: uncaught nlohmann exception)              */
+#define RT_EHIP         -4   /* HIP runtime error, no device, kernel image missing */
+#define RT_ENOMEM       -5
+#define RT_ELIMIT       -6   /* scene exceeds a device-side capacity (e.g. RT_MAX_CSG_LEAVES) */
+
+typedef struct rt_scene rt_scene;   /* device-resident scene + work queues */
+
+/* per-call counters (all optional, all totals over the call) */
+typedef struct rt_stats {
+	uint64_t rays_nearest;     /* BVH::findNearest calls   (bvh.cpp:72)  : primary + reflection + transmission */
+	uint64_t rays_shadow;      /* BVH::calcShadow calls    (bvh.cpp:123) */
+	uint64_t nodes_visited;    /* 64 B BVH nodes read, nearest + shadow (only when RT_FLAG_COUNTERS) */
+	uint64_t prim_tests;       /* primitive rayhit evaluations          (only when RT_FLAG_COUNTERS) */
+	uint64_t levels;           /* wavefront iterations executed (ray-tree depth reached + 1) */
+	uint64_t batch_splits;     /* times a pixel batch was re-run in halves because a ray queue overflowed */
+	float    gpu_ms;           /* hipEvent time of the whole call on `stream`, upload/download excluded */
+	float    nearest_ms;       /* hipEvent time spent in the nearest-hit traversal kernel (dominant kernel) */
+	float    shadow_ms;        /* hipEvent time spent in the shadow traversal kernel */
+	float    pad;
+} rt_stats;
+
+#define RT_FLAG_COUNTERS   1u   /* count nodes_visited / prim_tests in the traversal kernels (slower) */
+#define RT_FLAG_TIME_KERNELS 2u /* bracket each traversal launch with hipEvents to fill nearest_ms / shadow_ms */
+
+/* ------------------------------------------------------------------------------------------------------
+ * Host-side scene handling (no GPU needed).
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Restatement of choose_scene() (raytracer.cpp:117-305) that returns the scene as flat arrays instead of
+ * filling globals: parses `json_path`, loads textures / bump maps from `asset_dir` + the file names in the
+ * scene (the reference prefixes "scenes/", raytracer.cpp:22,206,232), builds the reference's BVH
+ * (bvh.cpp:6-70) and flattens it.  The result owns its arrays; release with rt_flat_scene_free. */
+int rt_load_scene_json(const char* json_path, const char* asset_dir, rt_flat_scene** out);
+/* Same, from JSON text already in memory. */
+int rt_load_scene_json_text(const char* json_text, size_t len, const char* asset_dir, rt_flat_scene** out);
+/* Binary form of the flat scene (little-endian dump of the arrays); the additive large-mesh ingest path of
+ * SURVEY.md section 8f-2, also how the golden scenes travel to the GPU box. */
+int rt_flat_scene_save(const rt_flat_scene* scene, const char* path);
+int rt_flat_scene_load(const char* path, rt_flat_scene** out);
+void rt_flat_scene_free(rt_flat_scene* scene);
+
+/* Camera basis exactly as setFacing() leaves it (q1.cpp:30-44); rotX/rotY are q1.cpp's rotationX/rotationY. */
+int rt_camera_setup(double fov, int width, int height, const float eye[3], float rotX, float rotY, rt_camera* out);
+
+/* RGB float -> 8-bit: clamp to [0,1], c*255+0.5 truncated, NaN -> 0.  `rgb` is W*H*3 with row 0 = BOTTOM
+ * row (the GL convention of q1.cpp:125-147); the BMP is written top row first.  The reference never writes
+ * a file; the layout is EasyBMP's BMP::WriteToFile (EasyBMP.cpp:424). */
+int rt_write_bmp(const char* path, const float* rgb, int width, int height);
+int rt_quantize_rgb8(const float* rgb, int width, int height, uint8_t* rgb8_top_down);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Device side.
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Number of usable GPUs (0 if none / no HIP runtime). */
+int rt_device_count(void);
+
+/* Copies the flat scene to HBM on `device` and allocates the handle's ray/hit queues.  Takes the place of the
+ * tail of choose_scene(), which leaves the scene in process globals (raytracer.cpp:29-32,304). */
+int rt_scene_upload(const rt_flat_scene* scene, int device, rt_scene** out);
+void rt_scene_free(rt_scene* scene);
+
+/* Renders a frame: the display() pixel loop (q1.cpp:130-147) over trace() (raytracer.cpp:307-329), i.e.
+ * generate -> [intersect -> shade -> shadow]* -> resolve on the GPU.
+ *   aa            sub-pixel grid per axis: 1 = s(x,y) (q1.cpp:51-53), 2 = the reference's 4x s_aa (q1.cpp:55-64),
+ *                 n = n*n samples at ((i+.5)/n, (j+.5)/n)
+ *   max_depth     MAX_REFLECTIONS (raytracer.h:7); the reference value is 16
+ *   tile_rank, tile_ranks   render only the 32x8-pixel tiles t with t % tile_ranks == tile_rank (multi-GPU
+ *                 sharding); the other pixels of rgb_dev are left untouched.  (0,1) = whole frame.
+ *   seed          seeds the counter-based generator that replaces rand() in arealight.cpp:5
+ *   rgb_dev       DEVICE buffer, width*height*3 floats, row 0 = bottom row; miss = background colour
+ * Enqueues on `stream`, waits for completion, fills *stats if not NULL. */
+int rt_render(rt_scene* scene, const rt_camera* camera, int width, int height, int aa, int max_depth,
+              int tile_rank, int tile_ranks, uint32_t seed, uint32_t flags, float* rgb_dev, void* stream, rt_stats* stats);
+/* Convenience: same, into a HOST buffer (allocates a temporary device frame). */
+int rt_render_host(rt_scene* scene, const rt_camera* camera, int width, int height, int aa, int max_depth,
+                   uint32_t seed, uint32_t flags, float* rgb_host, rt_stats* stats);
+
+/* trace() for n rays at once (raytracer.h:16, raytracer.cpp:307-329): ray i runs from e[i] towards s[i]
+ * (direction s-e, NOT normalised).  Outputs (each may be NULL): hit[i] = trace()'s return value,
+ * obj_id[i] = id of hitObject (-1 on a miss), t[i] = its ray parameter, rgb[i] = colour, with the caller's
+ * `background_colour` substitution on a miss already applied (q1.cpp:143-145).  Host buffers. */
+int rt_trace_batch(rt_scene* scene, const float* e, const float* s, size_t n, int max_depth, uint32_t seed, uint32_t flags,
+                   uint8_t* hit, int32_t* obj_id, float* t, float* rgb, rt_stats* stats);
+
+/* BVH::findNearest() for n rays (bvh.h:23, bvh.cpp:72-92): origin e[i], direction d[i] as given. */
+int rt_intersect_batch(rt_scene* scene, const float* e, const float* d, size_t n, uint32_t flags,
+                       uint8_t* hit, int32_t* obj_id, float* t, rt_stats* stats);
+
+/* shadowRay() for n queries (raytracer.h:18, raytracer.cpp:111-113 -> BVH::calcShadow, bvh.cpp:123-160):
+ * lit[i] = return value, shadow[i] = the attenuation colour on return (starts at (1,1,1)). */
+int rt_shadow_batch(rt_scene* scene, const float* point, const float* light_pos, size_t n, uint32_t flags,
+                    uint8_t* lit, float* shadow, rt_stats* stats);
+
+/* Multi-GPU frame assembly on rank 0: copies the pixels of the tiles owned by `tile_rank` from a rank's
+ * dense frame `src_dev` into `dst_dev` (both width*height*3 floats on the scene's device).  New: the
+ * reference is single-process; this is the de-interleave after the RCCL gather. */
+int rt_tiles_merge(rt_scene* scene, const float* src_dev, float* dst_dev, int width, int height, int tile_rank, int tile_ranks, void* stream);
+/* Packs / unpacks the owned tiles of a frame into a dense buffer of rt_tiles_count()*256*3 floats (gather payload). */
+int64_t rt_tiles_count(int width, int height, int tile_rank, int tile_ranks);
+int rt_tiles_pack(rt_scene* scene, const float* frame_dev, float* packed_dev, int width, int height, int tile_rank, int tile_ranks, void* stream);
+int rt_tiles_unpack(rt_scene* scene, const float* packed_dev, float* frame_dev, int width, int height, int tile_rank, int tile_ranks, void* stream);
+
+const char* rt_last_error(void);
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,487 @@
+// scene_loader.cpp -- host side: JSON scene -> flat scene IR (include/rt_scene.h).
+//
+// Restates, over flat arrays, what the reference does at load time:
+//   choose_scene            raytracer.cpp:117-305   (schema, defaults, object/light construction)
+//   create_csgNode          raytracer.cpp:46-105
+//   Sphere/Triangle/Box ctors, Mesh::setBox         objects.cpp:146-157,235-249,315-335
+//   csg_node::getBox        csg.cpp:56-85
+//   light ctors             objects.cpp:393-397,437-443 ; arealight.cpp:24-35,64-77
+//   BVH::BVH / splitNode / BVH_node / sortObjects   bvh.cpp:6-70,162-214
+// The tree is built with the reference's algorithm (median split on the longest axis, std::sort on
+// centroids, stop at <= 2 objects or depth 16) so that leaf contents and DFS order -- which decide ties
+// between equal-t hits -- are the reference's.  libstdc++'s std::sort is used on purpose: its permutation
+// for equal keys is part of the oracle's definition ("Ties").
+#include "rt_capi.h"
+#include "rt_vec.h"
+#include "bmp_io.h"
+#include "json_min.h"
+#include "host_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+using rt::vec3;
+using rtjson::Value;
+
+namespace rt {
+
+thread_local std::string g_lastError;
+void set_error(const std::string& s) { g_lastError = s; }
+
+void FlatSceneStore::link() {
+	rt_flat_scene& s = view;
+	s.n_planes = (int32_t)planes.size(); s.planes = planes.data();
+	s.n_spheres = (int32_t)spheres.size(); s.spheres = spheres.data();
+	s.n_tris = (int32_t)tris.size(); s.tris = tris.data();
+	s.n_boxes = (int32_t)boxes.size(); s.boxes = boxes.data();
+	s.n_csgs = (int32_t)csgs.size(); s.csgs = csgs.data();
+	s.n_csg_nodes = (int32_t)csg_nodes.size(); s.csg_nodes = csg_nodes.data();
+	s.n_meshes = (int32_t)meshes.size(); s.meshes = meshes.data();
+	s.n_mesh_tris = (int32_t)mesh_tris.size(); s.mesh_tris = mesh_tris.data();
+	s.n_uvs = (int32_t)uvs.size(); s.uvs = uvs.data();
+	s.n_materials = (int32_t)materials.size(); s.materials = materials.data();
+	s.n_lights = (int32_t)lights.size(); s.lights = lights.data();
+	s.n_textures = (int32_t)textures.size(); s.textures = textures.data();
+	s.n_texel_bytes = (int64_t)texels.size(); s.texels = texels.data();
+	s.n_bvh_nodes = (int32_t)bvh_nodes.size(); s.bvh_nodes = bvh_nodes.data();
+	s.n_leaf_prims = (int32_t)leaf_prims.size(); s.leaf_prims = leaf_prims.data();
+}
+
+}  // namespace rt
+
+namespace {
+
+vec3 to_vec3(const Value& v) { return vec3(v[0].f32(), v[1].f32(), v[2].f32()); }   // vector_to_vec3, raytracer.cpp:38-40
+void put3(float* dst, vec3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
+
+struct Box6 { float b[6]; };   // minX,maxX,minY,maxY,minZ,maxZ
+
+// An object as the BVH constructor sees it (bvh.cpp:10-28): its box, its centroid, and where it lives.
+struct BuildObj {
+	uint32_t type;      // RT_PRIM_*
+	int32_t src;        // index into the scene-order staging array of that type
+	Box6 box;
+	vec3 centroid;
+};
+
+struct Loader {
+	rt::FlatSceneStore* S;
+	std::string assetDir;
+	// scene-order staging (the BVH flatten re-emits these in leaf order)
+	std::vector<rt_sphere> spheres;
+	std::vector<rt_tri> tris;
+	std::vector<rt_box> boxes;
+	std::vector<rt_csg> csgs;
+	std::vector<BuildObj> bvhObjs;
+	int32_t nextBvhId = 0;
+
+	int addTexture(const std::string& file) {
+		rt::Image8 img;
+		rt::read_bmp(assetDir + file, img);   // failure leaves EasyBMP's 1x1 white image, silently (EasyBMP.cpp:685-695)
+		rt_texture t;
+		t.width = img.width; t.height = img.height; t.offset = (int64_t)S->texels.size();
+		S->texels.insert(S->texels.end(), img.rgb.begin(), img.rgb.end());
+		S->textures.push_back(t);
+		return (int)S->textures.size() - 1;
+	}
+
+	static Box6 triBox(const rt_tri& t) {   // objects.cpp:243-248 (std::min/max over an initializer_list)
+		Box6 b;
+		for (int a = 0; a < 3; a++) {
+			b.b[2 * a] = std::min({ t.p0[a], t.p1[a], t.p2[a] });
+			b.b[2 * a + 1] = std::max({ t.p0[a], t.p1[a], t.p2[a] });
+		}
+		return b;
+	}
+	static rt_tri makeTri(vec3 p0, vec3 p1, vec3 p2, int mat, int mesh) {   // Triangle::Triangle, objects.cpp:235-249
+		rt_tri t;
+		put3(t.p0, p0); put3(t.p1, p1); put3(t.p2, p2);
+		put3(t.n, rt::normalize(rt::cross(p1 - p0, p2 - p1)));
+		t.id = -1; t.mat = mat; t.mesh = mesh; t.uv = -1;
+		return t;
+	}
+	static Box6 boxFromPoints(vec3 p1, vec3 p2) {   // raytracer.cpp:71-79,244-252
+		Box6 b;
+		b.b[0] = std::min(p1.x, p2.x); b.b[1] = std::max(p1.x, p2.x);
+		b.b[2] = std::min(p1.y, p2.y); b.b[3] = std::max(p1.y, p2.y);
+		b.b[4] = std::min(p1.z, p2.z); b.b[5] = std::max(p1.z, p2.z);
+		return b;
+	}
+	static Box6 sphereBox(vec3 c, float r) {   // objects.cpp:151-156
+		Box6 b;
+		b.b[0] = c.x - r; b.b[1] = c.x + r; b.b[2] = c.y - r; b.b[3] = c.y + r; b.b[4] = c.z - r; b.b[5] = c.z + r;
+		return b;
+	}
+	static Box6 meshBox(const std::vector<rt_tri>& ts, size_t first, size_t count) {   // Mesh::setBox, objects.cpp:315-325
+		Box6 b = triBox(ts[first]);
+		for (size_t i = 1; i < count; i++) {
+			Box6 c = triBox(ts[first + i]);
+			b.b[0] = std::min(b.b[0], c.b[0]); b.b[2] = std::min(b.b[2], c.b[2]); b.b[4] = std::min(b.b[4], c.b[4]);
+			b.b[1] = std::max(b.b[1], c.b[1]); b.b[3] = std::max(b.b[3], c.b[3]); b.b[5] = std::max(b.b[5], c.b[5]);
+		}
+		return b;
+	}
+
+	// create_csgNode (raytracer.cpp:46-105) + csg_node::getBox (csg.cpp:56-85); emits nodes in post-order.
+	Box6 addCsgNode(const Value& nj, int& leaves) {
+		rt_csg_node node;
+		memset(&node, 0, sizeof node);
+		node.mesh = -1;
+		Box6 box;
+		memset(&box, 0, sizeof box);
+		if (nj.has("operation")) {
+			const Value& op = nj["operation"];
+			if (op.is("union")) node.kind = RT_CSG_UNION;
+			else if (op.is("intersection")) node.kind = RT_CSG_INTERSECTION;
+			else if (op.is("difference")) node.kind = RT_CSG_DIFFERENCE;
+			else throw std::runtime_error("csg: unknown operation");
+			Box6 b1 = addCsgNode(nj["first"], leaves);
+			Box6 b2 = addCsgNode(nj["second"], leaves);
+			if (node.kind == RT_CSG_DIFFERENCE) box = b1;
+			else if (node.kind == RT_CSG_UNION) {
+				for (int a = 0; a < 3; a++) { box.b[2 * a] = std::min(b1.b[2 * a], b2.b[2 * a]); box.b[2 * a + 1] = std::max(b1.b[2 * a + 1], b2.b[2 * a + 1]); }
+			} else {
+				for (int a = 0; a < 3; a++) { box.b[2 * a] = std::max(b1.b[2 * a], b2.b[2 * a]); box.b[2 * a + 1] = std::min(b1.b[2 * a + 1], b2.b[2 * a + 1]); }
+			}
+		} else {
+			leaves++;
+			const Value& type = nj["type"];
+			if (type.is("sphere")) {
+				vec3 c = to_vec3(nj["position"]);
+				float r = nj["radius"].f32();
+				node.kind = RT_CSG_SPHERE;
+				node.f[0] = c.x; node.f[1] = c.y; node.f[2] = c.z; node.f[3] = r;
+				box = sphereBox(c, r);
+			} else if (type.is("box")) {
+				box = boxFromPoints(to_vec3(nj["point1"]), to_vec3(nj["point2"]));
+				node.kind = RT_CSG_BOX;
+				memcpy(node.f, box.b, sizeof box.b);
+			} else if (type.is("mesh")) {
+				const Value& tj = nj["triangles"];
+				rt_mesh m;
+				m.tri_first = (int32_t)S->mesh_tris.size(); m.tri_count = (int32_t)tj.size(); m.tex = -1; m.mat = 0;
+				if (m.tri_count == 0) throw std::runtime_error("csg: mesh leaf without triangles");
+				int meshIdx = (int)S->meshes.size();
+				for (size_t i = 0; i < tj.size(); i++)
+					S->mesh_tris.push_back(makeTri(to_vec3(tj[i][0]), to_vec3(tj[i][1]), to_vec3(tj[i][2]), 0, meshIdx));
+				S->meshes.push_back(m);
+				node.kind = RT_CSG_MESH; node.mesh = meshIdx;
+				box = meshBox(S->mesh_tris, (size_t)m.tri_first, (size_t)m.tri_count);
+			} else throw std::runtime_error("csg: unknown leaf type");
+		}
+		S->csg_nodes.push_back(node);
+		return box;
+	}
+
+	// ---- BVH (bvh.cpp:37-70,162-214) ----
+	static Box6 unionBox(const std::vector<BuildObj>& all, const std::vector<int>& objs) {   // BVH_node::BVH_node
+		Box6 b = all[objs[0]].box;
+		for (size_t i = 1; i < objs.size(); i++) {
+			const Box6& c = all[objs[i]].box;
+			b.b[0] = std::min(b.b[0], c.b[0]); b.b[1] = std::max(b.b[1], c.b[1]);
+			b.b[2] = std::min(b.b[2], c.b[2]); b.b[3] = std::max(b.b[3], c.b[3]);
+			b.b[4] = std::min(b.b[4], c.b[4]); b.b[5] = std::max(b.b[5], c.b[5]);
+		}
+		return b;
+	}
+
+	// Returns the (child, count) reference of the subtree over `objs` whose box is `box`.
+	void buildNode(std::vector<int>& objs, const Box6& box, int depth, int32_t& childOut, int32_t& countOut) {
+		if (objs.size() <= 2 || depth >= RT_MAX_BVH_DEPTH) {   // bvh.cpp:39
+			childOut = ~(int32_t)S->leaf_prims.size();
+			countOut = (int32_t)objs.size();
+			for (int oi : objs) emitLeafPrim(bvhObjs[oi]);
+			return;
+		}
+		float lengthX = box.b[1] - box.b[0], lengthY = box.b[3] - box.b[2], lengthZ = box.b[5] - box.b[4];
+		int axis = (lengthX >= lengthY && lengthX >= lengthZ) ? 0 : (lengthY >= lengthZ ? 1 : 2);   // bvh.cpp:48-56
+		const std::vector<BuildObj>& all = bvhObjs;
+		std::sort(objs.begin(), objs.end(), [&all, axis](int a, int b) { return all[a].centroid[axis] < all[b].centroid[axis]; });
+		std::vector<int> left(objs.begin(), objs.begin() + objs.size() / 2);
+		std::vector<int> right(objs.begin() + objs.size() / 2, objs.end());
+		std::vector<int>().swap(objs);   // the reference keeps the parent's list alive; we do not need it
+		Box6 lb = unionBox(all, left), rb = unionBox(all, right);
+		int32_t self = (int32_t)S->bvh_nodes.size();
+		S->bvh_nodes.push_back(rt_bvh_node());
+		int32_t c0, n0, c1, n1;
+		buildNode(left, lb, depth + 1, c0, n0);
+		buildNode(right, rb, depth + 1, c1, n1);
+		rt_bvh_node& n = S->bvh_nodes[self];
+		memcpy(n.box[0], lb.b, sizeof lb.b); memcpy(n.box[1], rb.b, sizeof rb.b);
+		n.child[0] = c0; n.child[1] = c1; n.count[0] = n0; n.count[1] = n1;
+		childOut = self; countOut = 0;
+	}
+
+	void emitLeafPrim(const BuildObj& o) {
+		switch (o.type) {
+		case RT_PRIM_SPHERE: S->leaf_prims.push_back(RT_PRIM_REF(RT_PRIM_SPHERE, S->spheres.size())); S->spheres.push_back(spheres[o.src]); break;
+		case RT_PRIM_TRI: S->leaf_prims.push_back(RT_PRIM_REF(RT_PRIM_TRI, S->tris.size())); S->tris.push_back(tris[o.src]); break;
+		case RT_PRIM_BOX: S->leaf_prims.push_back(RT_PRIM_REF(RT_PRIM_BOX, S->boxes.size())); S->boxes.push_back(boxes[o.src]); break;
+		case RT_PRIM_CSG: S->leaf_prims.push_back(RT_PRIM_REF(RT_PRIM_CSG, S->csgs.size())); S->csgs.push_back(csgs[o.src]); break;
+		}
+	}
+
+	static rt_material parseMaterial(const Value& mj) {   // raytracer.cpp:149-165
+		rt_material m;
+		memset(&m, 0, sizeof m);
+		if (mj.has("ambient")) put3(m.ambient, to_vec3(mj["ambient"]));
+		if (mj.has("diffuse")) put3(m.diffuse, to_vec3(mj["diffuse"]));
+		if (mj.has("specular")) put3(m.specular, to_vec3(mj["specular"]));
+		if (mj.has("reflective")) put3(m.reflective, to_vec3(mj["reflective"]));
+		if (mj.has("transmissive")) put3(m.transmissive, to_vec3(mj["transmissive"]));
+		if (mj.has("shininess")) m.shininess = mj["shininess"].f32();
+		if (mj.has("refraction")) m.refraction = mj["refraction"].f32();
+		return m;
+	}
+
+	void load(const Value& scene) {
+		rt_flat_scene& V = S->view;
+		V.fov = 60; V.background[0] = V.background[1] = V.background[2] = 0;   // raytracer.cpp:24-25
+		const Value& camera = scene["camera"];
+		if (camera.has("field")) V.fov = camera["field"].number();
+		if (camera.has("background")) put3(V.background, to_vec3(camera["background"]));
+
+		// material 0 = Material() for csg leaves; object k uses material k+1
+		rt_material zero; memset(&zero, 0, sizeof zero);
+		S->materials.push_back(zero);
+
+		const Value& objects = scene["objects"];
+		// ids: planes first, then BVH objects in scene order (bvh.cpp:10-28)
+		int nPlanes = 0;
+		for (size_t i = 0; i < objects.size(); i++) if (objects[i]["type"].is("plane")) nPlanes++;
+		int planeId = 0;
+		nextBvhId = nPlanes;
+
+		for (size_t oi = 0; oi < objects.size(); oi++) {
+			const Value& object = objects[oi];
+			int mat = (int)S->materials.size();
+			S->materials.push_back(parseMaterial(object["material"]));
+			const Value& type = object["type"];
+			if (type.is("sphere") || type.is("bumpsphere")) {
+				rt_sphere s;
+				vec3 c = to_vec3(object["position"]);
+				put3(s.center, c); s.radius = object["radius"].f32();
+				s.id = nextBvhId++; s.mat = mat; s.bump_tex = -1; s.bump_depth = 0;
+				if (type.is("bumpsphere")) {   // raytracer.cpp:226-233
+					std::string file = object["bumpmap"].string();
+					s.bump_depth = object["bumpdepth"].f32();
+					s.bump_tex = addTexture(file);
+				}
+				BuildObj b; b.type = RT_PRIM_SPHERE; b.src = (int)spheres.size(); b.box = sphereBox(c, s.radius); b.centroid = c;
+				spheres.push_back(s); bvhObjs.push_back(b);
+			} else if (type.is("plane")) {
+				rt_plane p;
+				put3(p.point, to_vec3(object["position"])); put3(p.normal, to_vec3(object["normal"]));
+				p.id = planeId++; p.mat = mat;
+				S->planes.push_back(p);
+			} else if (type.is("mesh") || type.is("texturemesh")) {
+				const Value& tj = object["triangles"];
+				bool textured = type.is("texturemesh");
+				rt_mesh m;
+				m.tri_first = (int32_t)S->mesh_tris.size(); m.tri_count = (int32_t)tj.size(); m.tex = -1; m.mat = mat;
+				int meshIdx = (int)S->meshes.size();
+				if (textured) m.tex = addTexture(object["texture"].string());
+				for (size_t i = 0; i < tj.size(); i++) {
+					rt_tri t = makeTri(to_vec3(tj[i][0]), to_vec3(tj[i][1]), to_vec3(tj[i][2]), mat, meshIdx);
+					t.id = nextBvhId++;
+					if (textured) {   // raytracer.cpp:210-220
+						const Value& uvj = object["uvCoords"][i];
+						rt_uv uv;
+						for (int k = 0; k < 3; k++) { uv.uv[2 * k] = uvj[k][0].f32(); uv.uv[2 * k + 1] = uvj[k][1].f32(); }
+						t.uv = (int32_t)S->uvs.size();
+						S->uvs.push_back(uv);
+					}
+					BuildObj b; b.type = RT_PRIM_TRI; b.src = (int)tris.size(); b.box = triBox(t);
+					b.centroid = vec3((t.p0[0] + t.p1[0] + t.p2[0]) / 3, (t.p0[1] + t.p1[1] + t.p2[1]) / 3, (t.p0[2] + t.p1[2] + t.p2[2]) / 3);   // objects.cpp:267-271
+					tris.push_back(t); S->mesh_tris.push_back(t); bvhObjs.push_back(b);
+				}
+				S->meshes.push_back(m);
+			} else if (type.is("csgobject")) {
+				rt_csg c;
+				memset(&c, 0, sizeof c);
+				c.id = nextBvhId++; c.mat = mat; c.node_first = (int32_t)S->csg_nodes.size();
+				if (!object.has("operation")) throw std::runtime_error("csgobject without an operation");
+				int leaves = 0;
+				Box6 box = addCsgNode(object, leaves);
+				if (leaves > RT_MAX_CSG_LEAVES) throw std::runtime_error("csgobject has more leaves than RT_MAX_CSG_LEAVES");
+				c.node_count = (int32_t)S->csg_nodes.size() - c.node_first;
+				memcpy(c.b, box.b, sizeof box.b);
+				BuildObj b; b.type = RT_PRIM_CSG; b.src = (int)csgs.size(); b.box = box;
+				b.centroid = vec3((box.b[0] + box.b[1]) / 2, (box.b[2] + box.b[3]) / 2, (box.b[4] + box.b[5]) / 2);   // csg.cpp:32-36
+				csgs.push_back(c); bvhObjs.push_back(b);
+			} else if (type.is("box")) {
+				rt_box bx;
+				Box6 box = boxFromPoints(to_vec3(object["point1"]), to_vec3(object["point2"]));
+				memcpy(bx.b, box.b, sizeof box.b); bx.id = nextBvhId++; bx.mat = mat;
+				BuildObj b; b.type = RT_PRIM_BOX; b.src = (int)boxes.size(); b.box = box;
+				b.centroid = vec3((box.b[0] + box.b[1]) / 2, (box.b[2] + box.b[3]) / 2, (box.b[4] + box.b[5]) / 2);   // objects.cpp:363-367
+				boxes.push_back(bx); bvhObjs.push_back(b);
+			}
+			// unknown types are ignored, as in the reference's chain of ifs
+		}
+		V.n_objects = nextBvhId;
+
+		const Value& lights = scene["lights"];
+		for (size_t li = 0; li < lights.size(); li++) {
+			const Value& lj = lights[li];
+			rt_light L;
+			memset(&L, 0, sizeof L);
+			put3(L.colour, to_vec3(lj["color"]));
+			const Value& type = lj["type"];
+			if (type.is("ambient")) L.type = RT_LIGHT_AMBIENT;
+			else if (type.is("directional")) { L.type = RT_LIGHT_DIRECTIONAL; put3(L.direction, rt::normalize(to_vec3(lj["direction"]))); }
+			else if (type.is("point")) { L.type = RT_LIGHT_POINT; put3(L.position, to_vec3(lj["position"])); }
+			else if (type.is("spot")) {
+				L.type = RT_LIGHT_SPOT;
+				put3(L.position, to_vec3(lj["position"]));
+				put3(L.direction, rt::normalize(to_vec3(lj["direction"])));
+				L.cutoff = lj["cutoff"].f32();
+				L.cos_cutoff = cos(L.cutoff * 3.14159265358979323846264338327950288 / 180);   // objects.cpp:451 (objects.h:9)
+			} else if (type.is("rectangular")) {   // arealight.cpp:24-35
+				L.type = RT_LIGHT_RECT;
+				vec3 normal = to_vec3(lj["normal"]), orientation = to_vec3(lj["orientation"]);
+				put3(L.position, to_vec3(lj["position"])); put3(L.normal, normal);
+				L.width = lj["width"].f32(); L.height = lj["height"].f32(); L.samples = lj["samples"].i32();
+				vec3 planeX = rt::normalize(rt::cross(orientation, normal));
+				vec3 planeY = rt::normalize(rt::cross(normal, planeX));
+				put3(L.planeX, planeX); put3(L.planeY, planeY);
+			} else if (type.is("circular")) {   // arealight.cpp:64-77
+				L.type = RT_LIGHT_CIRC;
+				vec3 normal = to_vec3(lj["normal"]);
+				put3(L.position, to_vec3(lj["position"])); put3(L.normal, normal);
+				L.radius = lj["radius"].f32(); L.samples = lj["samples"].i32();
+				vec3 planeX = rt::normalize(rt::cross(vec3(0, 1, 0), normal));
+				if (std::isnan(planeX.x)) planeX = rt::normalize(rt::cross(vec3(0, 0, 1), normal));
+				vec3 planeY = rt::normalize(rt::cross(normal, planeX));
+				put3(L.planeX, planeX); put3(L.planeY, planeY);
+			} else continue;
+			S->lights.push_back(L);
+		}
+
+		// bvh = new BVH(Objects)  (raytracer.cpp:304).  An all-plane scene dereferences objects[0] in the
+		// reference (bvh.cpp:164) and crashes; here it yields an empty tree.
+		V.root_child = -1; V.root_count = 0;
+		memset(V.root_box, 0, sizeof V.root_box);
+		if (!bvhObjs.empty()) {
+			std::vector<int> all(bvhObjs.size());
+			for (size_t i = 0; i < all.size(); i++) all[i] = (int)i;
+			Box6 rootBox = unionBox(bvhObjs, all);
+			memcpy(V.root_box, rootBox.b, sizeof rootBox.b);
+			buildNode(all, rootBox, 0, V.root_child, V.root_count);
+		}
+		S->link();
+	}
+};
+
+int loadFromText(const std::string& text, const char* assetDir, rt_flat_scene** out) {
+	if (!out) { rt::set_error("out is NULL"); return RT_EINVAL; }
+	*out = nullptr;
+	auto* store = new rt::FlatSceneStore();
+	try {
+		Value scene = rtjson::Parser::parse(text);
+		Loader L;
+		L.S = store;
+		L.assetDir = assetDir ? assetDir : "";
+		if (!L.assetDir.empty() && L.assetDir.back() != '/') L.assetDir += '/';
+		L.load(scene);
+	} catch (const std::exception& e) {
+		delete store;
+		rt::set_error(std::string("scene: ") + e.what());
+		return RT_EPARSE;
+	}
+	*out = &store->view;
+	return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return rt::g_lastError.c_str(); }
+const char* rt_version(void) { return "raytracer_amd 0.1 (gfx950)"; }
+
+int rt_load_scene_json_text(const char* json_text, size_t len, const char* asset_dir, rt_flat_scene** out) {
+	if (!json_text) { rt::set_error("json_text is NULL"); return RT_EINVAL; }
+	return loadFromText(std::string(json_text, len), asset_dir, out);
+}
+
+int rt_load_scene_json(const char* json_path, const char* asset_dir, rt_flat_scene** out) {
+	if (!json_path) { rt::set_error("json_path is NULL"); return RT_EINVAL; }
+	std::ifstream in(json_path, std::ios::binary);
+	if (!in.is_open()) { rt::set_error(std::string("Unable to open scene file ") + json_path); return RT_EIO; }
+	std::stringstream ss;
+	ss << in.rdbuf();
+	std::string dir;
+	if (asset_dir) dir = asset_dir;
+	else { std::string p(json_path); size_t k = p.find_last_of('/'); dir = k == std::string::npos ? "" : p.substr(0, k + 1); }
+	return loadFromText(ss.str(), dir.c_str(), out);
+}
+
+void rt_flat_scene_free(rt_flat_scene* scene) {
+	if (scene) delete rt::FlatSceneStore::from_view(scene);
+}
+
+}  // extern "C"
+
+// ---- binary form -------------------------------------------------------------------------------------
+static const char kMagic[8] = { 'R', 'T', 'S', 'C', '0', '0', '0', '2' };
+
+template <class T> static bool wr(FILE* f, const T* p, int64_t count) {
+	uint64_t n = count > 0 ? (uint64_t)count : 0;
+	if (fwrite(&n, 8, 1, f) != 1) return false;
+	return n == 0 || (p && fwrite(p, sizeof(T), n, f) == n);
+}
+template <class T> static bool rd(FILE* f, std::vector<T>& v) {
+	uint64_t n = 0;
+	if (fread(&n, 8, 1, f) != 1) return false;
+	if (n > (1ull << 36) / sizeof(T)) return false;
+	v.resize(n);
+	return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+
+extern "C" {
+
+int rt_flat_scene_save(const rt_flat_scene* scene, const char* path) {
+	if (!scene || !path) { rt::set_error("NULL argument"); return RT_EINVAL; }
+	FILE* f = fopen(path, "wb");
+	if (!f) { rt::set_error(std::string("cannot write ") + path); return RT_EIO; }
+	const rt_flat_scene& V = *scene;
+	bool ok = fwrite(kMagic, 8, 1, f) == 1 && fwrite(&V.fov, 8, 1, f) == 1 && fwrite(V.background, 12, 1, f) == 1 &&
+	          fwrite(&V.n_objects, 4, 1, f) == 1 && fwrite(V.root_box, 24, 1, f) == 1 && fwrite(&V.root_child, 4, 1, f) == 1 &&
+	          fwrite(&V.root_count, 4, 1, f) == 1;
+	ok = ok && wr(f, V.planes, V.n_planes) && wr(f, V.spheres, V.n_spheres) && wr(f, V.tris, V.n_tris) && wr(f, V.boxes, V.n_boxes) &&
+	     wr(f, V.csgs, V.n_csgs) && wr(f, V.csg_nodes, V.n_csg_nodes) && wr(f, V.meshes, V.n_meshes) && wr(f, V.mesh_tris, V.n_mesh_tris) &&
+	     wr(f, V.uvs, V.n_uvs) && wr(f, V.materials, V.n_materials) && wr(f, V.lights, V.n_lights) && wr(f, V.textures, V.n_textures) &&
+	     wr(f, V.texels, V.n_texel_bytes) && wr(f, V.bvh_nodes, V.n_bvh_nodes) && wr(f, V.leaf_prims, V.n_leaf_prims);
+	fclose(f);
+	if (!ok) { rt::set_error(std::string("short write to ") + path); return RT_EIO; }
+	return RT_OK;
+}
+
+int rt_flat_scene_load(const char* path, rt_flat_scene** out) {
+	if (!out || !path) { rt::set_error("NULL argument"); return RT_EINVAL; }
+	*out = nullptr;
+	FILE* f = fopen(path, "rb");
+	if (!f) { rt::set_error(std::string("Unable to open scene file ") + path); return RT_EIO; }
+	auto* S = new rt::FlatSceneStore();
+	rt_flat_scene& V = S->view;
+	char magic[8];
+	bool ok = fread(magic, 8, 1, f) == 1 && !memcmp(magic, kMagic, 8) && fread(&V.fov, 8, 1, f) == 1 && fread(V.background, 12, 1, f) == 1 &&
+	          fread(&V.n_objects, 4, 1, f) == 1 && fread(V.root_box, 24, 1, f) == 1 && fread(&V.root_child, 4, 1, f) == 1 &&
+	          fread(&V.root_count, 4, 1, f) == 1;
+	ok = ok && rd(f, S->planes) && rd(f, S->spheres) && rd(f, S->tris) && rd(f, S->boxes) && rd(f, S->csgs) && rd(f, S->csg_nodes) &&
+	     rd(f, S->meshes) && rd(f, S->mesh_tris) && rd(f, S->uvs) && rd(f, S->materials) && rd(f, S->lights) && rd(f, S->textures) &&
+	     rd(f, S->texels) && rd(f, S->bvh_nodes) && rd(f, S->leaf_prims);
+	fclose(f);
+	if (!ok) { delete S; rt::set_error(std::string("not a flat scene file or truncated: ") + path); return RT_EPARSE; }
+	S->link();
+	*out = &S->view;
+	return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// raytracer_api.cpp -- the reference's Raytracer API (raytracer.h:12-18, raytracer.cpp:24-32,111-133,307-329) on top
+// of the C-ABI: a process-global scene, choose_scene() with the reference's messages and exit(EXIT_FAILURE) on a
+// missing file, and single-ray trace()/shadowRay() served by the GPU (batches of one).  No CPU path is involved.
+#include "rt_capi.h"
+#include "host_internal.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+
+namespace {
+const char* PATH = "scenes/";   // raytracer.cpp:22
+double g_fov = 60;              // raytracer.cpp:24
+float g_background[3] = { 0, 0, 0 };
+rt_flat_scene* g_flat = nullptr;
+rt_scene* g_scene = nullptr;
+
+const char* typeName(const rt_flat_scene* s, int id) {
+	// names as Object::type holds them (objects.cpp:150,196,236,332; csg.cpp:5)
+	for (int i = 0; i < s->n_planes; i++) if (s->planes[i].id == id) return "plane";
+	for (int i = 0; i < s->n_spheres; i++) if (s->spheres[i].id == id) return "sphere";
+	for (int i = 0; i < s->n_boxes; i++) if (s->boxes[i].id == id) return "box";
+	for (int i = 0; i < s->n_csgs; i++) if (s->csgs[i].id == id) return "csgobject";
+	return "triangle";
+}
+}  // namespace
+
+extern "C" {
+
+double* rtapi_fov(void) { return &g_fov; }
+float* rtapi_background_colour(void) { return g_background; }
+rt_scene* rtapi_scene(void) { return g_scene; }
+const rt_flat_scene* rtapi_flat_scene(void) { return g_flat; }
+
+void rtapi_choose_scene(const char* fn) {
+	if (fn == nullptr) {
+		std::cout << "Using default input file " << PATH << "c.json\n";
+		fn = "c";
+	}
+	std::cout << "Loading scene " << fn << std::endl;
+	std::string fname = PATH + std::string(fn) + ".json";
+	rt_flat_scene* flat = nullptr;
+	int rc = rt_load_scene_json(fname.c_str(), PATH, &flat);
+	if (rc == RT_EIO) {
+		std::cout << "Unable to open scene file " << fname << std::endl;
+		exit(EXIT_FAILURE);
+	}
+	if (rc != RT_OK) {   // the reference dies on an uncaught json exception here
+		std::cerr << rt_last_error() << std::endl;
+		abort();
+	}
+	if (g_scene) rt_scene_free(g_scene);
+	if (g_flat) rt_flat_scene_free(g_flat);
+	g_flat = flat; g_scene = nullptr;
+	g_fov = flat->fov;
+	for (int i = 0; i < 3; i++) g_background[i] = flat->background[i];
+	const char* dev = getenv("RT_DEVICE");
+	rc = rt_scene_upload(flat, dev ? atoi(dev) : 0, &g_scene);
+	if (rc != RT_OK) {
+		std::cerr << "raytracer_amd: " << rt_last_error() << std::endl;
+		exit(EXIT_FAILURE);
+	}
+}
+
+int rtapi_trace(const float* e, const float* s, float* colour, int pick, int reflectionCount) {
+	if (!g_scene) { std::cerr << "raytracer_amd: trace() before choose_scene()" << std::endl; abort(); }
+	if (reflectionCount > RT_MAX_REFLECTIONS) {   // raytracer.cpp:308-313
+		if (pick) std::cout << "Maximum number of reflections reached." << std::endl;
+		colour[0] = colour[1] = colour[2] = 0;
+		return 0;
+	}
+	uint8_t hit = 0; int32_t id = -1; float t = 0, rgb[3] = { 0, 0, 0 };
+	int rc = rt_trace_batch(g_scene, e, s, 1, RT_MAX_REFLECTIONS - (reflectionCount > 0 ? reflectionCount : 0), 1, 0, &hit, &id, &t, rgb, nullptr);
+	if (rc != RT_OK) { std::cerr << "raytracer_amd: " << rt_last_error() << std::endl; abort(); }
+	if (!hit) return 0;   // colour untouched on a miss, like the reference
+	if (pick) {   // raytracer.cpp:323-324 (the deeper narration of objects.cpp is not reproduced)
+		float p[3];
+		for (int i = 0; i < 3; i++) p[i] = e[i] + t * (s[i] - e[i]);
+		std::cout << "object " << typeName(g_flat, id) << " hit at {" << p[0] << ", " << p[1] << ", " << p[2] << "}" << std::endl;
+	}
+	colour[0] = rgb[0]; colour[1] = rgb[1]; colour[2] = rgb[2];
+	return 1;
+}
+
+int rtapi_shadow_ray(const float* point, const float* lightPos, float* shadow) {
+	if (!g_scene) { std::cerr << "raytracer_amd: shadowRay() before choose_scene()" << std::endl; abort(); }
+	uint8_t lit = 0; float sh[3];
+	int rc = rt_shadow_batch(g_scene, point, lightPos, 1, 0, &lit, sh, nullptr);
+	if (rc != RT_OK) { std::cerr << "raytracer_amd: " << rt_last_error() << std::endl; abort(); }
+	// the reference multiplies the caller's running attenuation in place (bvh.cpp:152)
+	for (int i = 0; i < 3; i++) shadow[i] *= sh[i];
+	return lit;
+}
+
+}  // extern "C"

@@ -1,0 +1,454 @@
+// rt_capi_device.hip -- device half of the C-ABI (include/rt_capi.h): scene upload and the host loop that drives
+// the wavefront pipeline of rt_kernels.hip.  Compiled by hipcc; no CPU fallback exists: without a usable HIP
+// device every entry point here fails with RT_EHIP.
+#include "rt_capi.h"
+#include "rt_kernels.h"
+#include "host/host_internal.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace {
+
+#define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rt::set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); return RT_EHIP; } } while (0)
+
+uint32_t envU32(const char* name, uint32_t dflt) {
+	const char* v = getenv(name);
+	if (!v || !*v) return dflt;
+	unsigned long long x = strtoull(v, nullptr, 10);
+	return x == 0 || x > 0x7fffffffull ? dflt : (uint32_t)x;
+}
+
+}  // namespace
+
+struct rt_scene {
+	int device = 0;
+	DevScene dev{};
+	bool hasCsg = false;
+	std::vector<void*> allocs;
+	// lights, split by how their shadow rays are generated
+	int32_t* pointLights = nullptr;
+	uint32_t nPointLights = 0;
+	std::vector<std::pair<int, uint32_t>> areaLights;   // (light index, samples)
+	uint64_t shadowRaysPerSurface = 0;
+	// queues
+	uint32_t qcap = 0;
+	RtQueue ray[2]{}, hitq{}, surfq{};
+	RtCounters* ctr = nullptr;       // device
+	RtCounters* ctrHost = nullptr;   // pinned
+	RtAccum accum{};
+	hipEvent_t ev[6]{};              // 0,1 whole call; 2,3 nearest kernel; 4,5 shadow kernels
+
+	template <class T> int upload(const T* src, int64_t count, const T** dst) {
+		*dst = nullptr;
+		size_t bytes = (size_t)std::max<int64_t>(count, 1) * sizeof(T);
+		void* p = nullptr;
+		HIPCHK(hipMalloc(&p, bytes));
+		allocs.push_back(p);
+		if (count > 0) HIPCHK(hipMemcpy(p, src, (size_t)count * sizeof(T), hipMemcpyHostToDevice));
+		else HIPCHK(hipMemset(p, 0, bytes));
+		*dst = static_cast<const T*>(p);
+		return RT_OK;
+	}
+	int allocQueue(RtQueue& q, int comps) {
+		void* p = nullptr;
+		HIPCHK(hipMalloc(&p, (size_t)comps * qcap * sizeof(float)));
+		allocs.push_back(p);
+		q.f = static_cast<float*>(p); q.cap = qcap;
+		return RT_OK;
+	}
+	int ensureAccum(uint32_t npix) {
+		if (accum.npix >= npix && accum.rgb) return RT_OK;
+		if (accum.rgb) { hipFree(accum.rgb); hipFree(accum.nonfinite); accum.rgb = nullptr; accum.nonfinite = nullptr; accum.npix = 0; }
+		HIPCHK(hipMalloc((void**)&accum.rgb, (size_t)npix * 3 * sizeof(unsigned long long)));
+		HIPCHK(hipMalloc((void**)&accum.nonfinite, (size_t)npix));
+		HIPCHK(hipMemset(accum.rgb, 0, (size_t)npix * 3 * sizeof(unsigned long long)));
+		HIPCHK(hipMemset(accum.nonfinite, 0, (size_t)npix));
+		accum.npix = npix;
+		return RT_OK;
+	}
+};
+
+namespace {
+
+int treeDepth(const rt_flat_scene* s) {
+	if (s->root_child < 0) return 0;
+	int maxDepth = 0;
+	std::vector<std::pair<int32_t, int>> st;
+	st.push_back({ s->root_child, 1 });
+	while (!st.empty()) {
+		auto [n, d] = st.back();
+		st.pop_back();
+		maxDepth = std::max(maxDepth, d);
+		for (int k = 0; k < 2; k++)
+			if (s->bvh_nodes[n].child[k] >= 0) st.push_back({ s->bvh_nodes[n].child[k], d + 1 });
+	}
+	return maxDepth;
+}
+
+// Where a call's rays come from and where first-level results go.
+struct Source {
+	bool camera = false;
+	rt_camera cam{};
+	int W = 0, H = 0, aa = 1, tileRank = 0, tileRanks = 1;
+	const float* a = nullptr; const float* b = nullptr;   // device arrays for ray batches (origin, target)
+	uint8_t* outHit = nullptr; int32_t* outId = nullptr; float* outT = nullptr;
+};
+
+struct Run {
+	rt_scene* sc; hipStream_t st; Source src; int maxDepth; uint32_t seed; uint32_t flags; uint32_t aaSq;
+	rt_stats stats{};
+
+	int syncCounters() {
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(sc->ctrHost, sc->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));
+		return RT_OK;
+	}
+
+	// One batch of first-level rays [r0, r0+cnt) through all levels.  Returns 1 if a queue overflowed.
+	int levels(uint32_t r0, uint32_t cnt) {
+		const bool count = (flags & RT_FLAG_COUNTERS) != 0, timeK = (flags & RT_FLAG_TIME_KERNELS) != 0;
+		int cur = 0;
+		if (src.camera) rtk_generate(st, src.cam, src.W, src.H, src.aa, src.tileRank, src.tileRanks, r0, cnt, sc->ray[0]);
+		else rtk_load_rays(st, src.a + 3 * (size_t)r0, src.b + 3 * (size_t)r0, cnt, 1, sc->ray[0], r0);
+		uint32_t n = cnt;
+		bool shadowPending = false;
+		uint64_t nearRays = 0, shadowRays = 0, nLevels = 0;
+		for (int level = 0; level <= maxDepth && n > 0; level++) {
+			HIPCHK(hipMemsetAsync(sc->ctr, 0, 2 * sizeof(uint32_t), st));   // next_count, surf_count
+			if (timeK) HIPCHK(hipEventRecord(sc->ev[2], st));
+			rtk_intersect(st, sc->dev, sc->hasCsg, count, sc->ray[cur], n, sc->hitq, sc->ctr);
+			if (timeK) HIPCHK(hipEventRecord(sc->ev[3], st));
+			rtk_shade(st, sc->dev, sc->hasCsg, sc->ray[cur], sc->hitq, n, sc->ray[cur ^ 1], sc->surfq, sc->ctr, sc->accum, aaSq, maxDepth,
+			          sc->shadowRaysPerSurface > 0, level == 0 ? src.outHit : nullptr, src.outId, src.outT);
+			if (int rc = syncCounters()) return rc;
+			if (timeK) {
+				float ms = 0;
+				HIPCHK(hipEventElapsedTime(&ms, sc->ev[2], sc->ev[3])); stats.nearest_ms += ms;
+				if (shadowPending) { HIPCHK(hipEventElapsedTime(&ms, sc->ev[4], sc->ev[5])); stats.shadow_ms += ms; shadowPending = false; }
+			}
+			if (sc->ctrHost->overflow) return 1;
+			nLevels++;
+			// inactive slots of a partial edge tile are not rays
+			nearRays += n;
+			const uint32_t nsurf = sc->ctrHost->surf_count;
+			if (nsurf > 0 && sc->shadowRaysPerSurface > 0) {
+				if (timeK) HIPCHK(hipEventRecord(sc->ev[4], st));
+				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, sc->surfq, nsurf, sc->pointLights, sc->nPointLights, sc->accum, aaSq, sc->ctr);
+				for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, count, sc->surfq, nsurf, al.first, al.second, seed, sc->accum, aaSq, sc->ctr);
+				if (timeK) { HIPCHK(hipEventRecord(sc->ev[5], st)); shadowPending = true; }
+				shadowRays += (uint64_t)nsurf * sc->shadowRaysPerSurface;
+			}
+			n = sc->ctrHost->next_count;
+			cur ^= 1;
+		}
+		if (shadowPending) {
+			float ms = 0;
+			HIPCHK(hipEventSynchronize(sc->ev[5]));
+			HIPCHK(hipEventElapsedTime(&ms, sc->ev[4], sc->ev[5])); stats.shadow_ms += ms;
+		}
+		stats.rays_nearest += nearRays; stats.rays_shadow += shadowRays; stats.levels = std::max<uint64_t>(stats.levels, nLevels);
+		return RT_OK;
+	}
+
+	// Runs [r0, r0+cnt); on a queue overflow discards what the batch accumulated and re-runs it in two halves.
+	int batch(uint32_t r0, uint32_t cnt) {
+		const rt_stats saved = stats;
+		int rc = levels(r0, cnt);
+		if (rc != 1) return rc;
+		stats = saved;
+		stats.batch_splits++;
+		HIPCHK(hipMemsetAsync(&sc->ctr->overflow, 0, sizeof(uint32_t), st));
+		// clear this batch's pixels (resolve with no destination only zeroes the accumulators)
+		rtk_resolve(st, sc->accum, src.W, src.H, src.tileRank, src.tileRanks, r0 / aaSq, cnt / aaSq, aaSq, src.camera ? 0 : 1, nullptr);
+		if (cnt <= aaSq) { rt::set_error("ray queue too small for the ray tree of a single pixel (raise RT_QUEUE_RAYS)"); return RT_ELIMIT; }
+		const uint32_t half = std::max(aaSq, (cnt / 2 / aaSq) * aaSq);
+		if (int r1 = batch(r0, half)) return r1;
+		return batch(r0 + half, cnt - half);
+	}
+
+	int all(uint64_t totalRays) {
+		const uint32_t perBatch = std::max<uint32_t>(aaSq, (sc->qcap / 2 / (256 * aaSq)) * 256 * aaSq);
+		for (uint64_t r0 = 0; r0 < totalRays; r0 += perBatch) {
+			const uint32_t cnt = (uint32_t)std::min<uint64_t>(perBatch, totalRays - r0);
+			if (int rc = batch((uint32_t)r0, cnt)) return rc;
+		}
+		return RT_OK;
+	}
+};
+
+int begin(rt_scene* sc, hipStream_t st, uint32_t flags) {
+	HIPCHK(hipSetDevice(sc->device));
+	HIPCHK(hipMemsetAsync(sc->ctr, 0, sizeof(RtCounters), st));
+	HIPCHK(hipEventRecord(sc->ev[0], st));
+	(void)flags;
+	return RT_OK;
+}
+int finish(rt_scene* sc, hipStream_t st, Run& run, rt_stats* stats) {
+	HIPCHK(hipEventRecord(sc->ev[1], st));
+	if (run.flags & RT_FLAG_COUNTERS) HIPCHK(hipMemcpyAsync(sc->ctrHost, sc->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	HIPCHK(hipEventElapsedTime(&run.stats.gpu_ms, sc->ev[0], sc->ev[1]));
+	if (run.flags & RT_FLAG_COUNTERS) { run.stats.nodes_visited = sc->ctrHost->nodes; run.stats.prim_tests = sc->ctrHost->prims; }
+	if (stats) *stats = run.stats;
+	return RT_OK;
+}
+
+int64_t localTiles(int W, int H, int rank, int ranks) {
+	const int64_t T = (int64_t)((W + 31) / 32) * ((H + 7) / 8);
+	return rank < T ? (T - rank + ranks - 1) / ranks : 0;
+}
+// pixels of the image that fall into this rank's tiles (edge tiles may be partial)
+int64_t ownedPixels(int W, int H, int rank, int ranks) {
+	const int64_t tilesX = (W + 31) / 32, T = tilesX * ((H + 7) / 8);
+	int64_t n = 0;
+	for (int64_t t = rank; t < T; t += ranks) {
+		const int64_t tx = t % tilesX, ty = t / tilesX;
+		n += std::min<int64_t>(32, W - tx * 32) * std::min<int64_t>(8, H - ty * 8);
+	}
+	return n;
+}
+
+struct DevBuf {   // scoped device allocation
+	void* p = nullptr;
+	~DevBuf() { if (p) hipFree(p); }
+	int alloc(size_t bytes) { HIPCHK(hipMalloc(&p, std::max<size_t>(bytes, 16))); return RT_OK; }
+	template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rt_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
+	if (!out) { rt::set_error("rt_scene_upload: out is NULL"); return RT_EINVAL; }
+	*out = nullptr;
+	if (int rc = rt::validate_flat_scene(s)) return rc;
+	const int depth = treeDepth(s);
+	if (depth > RT_STACK_DEPTH) { rt::set_error("BVH deeper than the device traversal stack (RT_STACK_DEPTH)"); return RT_ELIMIT; }
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { rt::set_error("no HIP device available: the MI355X path has no CPU fallback"); return RT_EHIP; }
+	if (device < 0 || device >= ndev) { rt::set_error("rt_scene_upload: no such device"); return RT_EINVAL; }
+	HIPCHK(hipSetDevice(device));
+	rt_scene* sc = new rt_scene();
+	sc->device = device;
+	auto fail = [&](int rc) { rt_scene_free(sc); return rc; };
+	DevScene& D = sc->dev;
+	int rc;
+	if ((rc = sc->upload(s->planes, s->n_planes, &D.planes))) return fail(rc);
+	if ((rc = sc->upload(s->spheres, s->n_spheres, &D.spheres))) return fail(rc);
+	if ((rc = sc->upload(s->tris, s->n_tris, &D.tris))) return fail(rc);
+	if ((rc = sc->upload(s->boxes, s->n_boxes, &D.boxes))) return fail(rc);
+	if ((rc = sc->upload(s->csgs, s->n_csgs, &D.csgs))) return fail(rc);
+	if ((rc = sc->upload(s->csg_nodes, s->n_csg_nodes, &D.csg_nodes))) return fail(rc);
+	if ((rc = sc->upload(s->meshes, s->n_meshes, &D.meshes))) return fail(rc);
+	if ((rc = sc->upload(s->mesh_tris, s->n_mesh_tris, &D.mesh_tris))) return fail(rc);
+	if ((rc = sc->upload(s->uvs, s->n_uvs, &D.uvs))) return fail(rc);
+	if ((rc = sc->upload(s->materials, s->n_materials, &D.materials))) return fail(rc);
+	if ((rc = sc->upload(s->lights, s->n_lights, &D.lights))) return fail(rc);
+	if ((rc = sc->upload(s->textures, s->n_textures, &D.textures))) return fail(rc);
+	if ((rc = sc->upload(s->texels, s->n_texel_bytes, &D.texels))) return fail(rc);
+	if ((rc = sc->upload(s->bvh_nodes, s->n_bvh_nodes, &D.nodes))) return fail(rc);
+	if ((rc = sc->upload(s->leaf_prims, s->n_leaf_prims, &D.leaf_prims))) return fail(rc);
+	D.n_planes = s->n_planes; D.n_lights = s->n_lights;
+	D.root_child = s->root_child; D.root_count = s->root_count;
+	memcpy(D.root_box, s->root_box, sizeof D.root_box);
+	memcpy(D.background, s->background, sizeof D.background);
+	sc->hasCsg = s->n_csgs > 0;
+
+	std::vector<int32_t> pl;
+	for (int i = 0; i < s->n_lights; i++) {
+		const rt_light& L = s->lights[i];
+		if (L.type == RT_LIGHT_DIRECTIONAL || L.type == RT_LIGHT_POINT || L.type == RT_LIGHT_SPOT) { pl.push_back(i); sc->shadowRaysPerSurface += 1; }
+		else if ((L.type == RT_LIGHT_RECT || L.type == RT_LIGHT_CIRC) && L.samples > 0) { sc->areaLights.push_back({ i, (uint32_t)L.samples }); sc->shadowRaysPerSurface += (uint64_t)L.samples; }
+	}
+	sc->nPointLights = (uint32_t)pl.size();
+	const int32_t* plDev = nullptr;
+	if ((rc = sc->upload(pl.data(), (int64_t)pl.size(), &plDev))) return fail(rc);
+	sc->pointLights = const_cast<int32_t*>(plDev);
+
+	sc->qcap = std::max<uint32_t>(1024, envU32("RT_QUEUE_RAYS", 8u << 20));
+	if ((rc = sc->allocQueue(sc->ray[0], RQ_COMPS))) return fail(rc);
+	if ((rc = sc->allocQueue(sc->ray[1], RQ_COMPS))) return fail(rc);
+	if ((rc = sc->allocQueue(sc->hitq, HQ_COMPS))) return fail(rc);
+	if ((rc = sc->allocQueue(sc->surfq, SQ_COMPS))) return fail(rc);
+	{
+		void* p = nullptr;
+		hipError_t e = hipMalloc(&p, sizeof(RtCounters));
+		if (e != hipSuccess) { rt::set_error("hipMalloc counters failed"); return fail(RT_EHIP); }
+		sc->allocs.push_back(p);
+		sc->ctr = static_cast<RtCounters*>(p);
+		e = hipHostMalloc((void**)&sc->ctrHost, sizeof(RtCounters), hipHostMallocDefault);
+		if (e != hipSuccess) { rt::set_error("hipHostMalloc failed"); return fail(RT_EHIP); }
+		for (auto& ev : sc->ev)
+			if (hipEventCreate(&ev) != hipSuccess) { rt::set_error("hipEventCreate failed"); return fail(RT_EHIP); }
+	}
+	*out = sc;
+	return RT_OK;
+}
+
+void rt_scene_free(rt_scene* sc) {
+	if (!sc) return;
+	hipSetDevice(sc->device);
+	for (void* p : sc->allocs) hipFree(p);
+	if (sc->accum.rgb) hipFree(sc->accum.rgb);
+	if (sc->accum.nonfinite) hipFree(sc->accum.nonfinite);
+	if (sc->ctrHost) hipHostFree(sc->ctrHost);
+	for (auto& ev : sc->ev) if (ev) hipEventDestroy(ev);
+	delete sc;
+}
+
+int rt_render(rt_scene* sc, const rt_camera* camera, int width, int height, int aa, int max_depth, int tile_rank, int tile_ranks,
+              uint32_t seed, uint32_t flags, float* rgb_dev, void* stream, rt_stats* stats) {
+	if (!sc || !camera || !rgb_dev || width <= 0 || height <= 0 || aa < 1 || aa > 16 || max_depth < 0 || max_depth > 30 ||
+	    tile_ranks < 1 || tile_rank < 0 || tile_rank >= tile_ranks || (int64_t)width * height > (1ll << 31) / (aa * aa)) {
+		rt::set_error("rt_render: bad argument");
+		return RT_EINVAL;
+	}
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	if (int rc = begin(sc, st, flags)) return rc;
+	if (int rc = sc->ensureAccum((uint32_t)(width * height))) return rc;
+	Run run{ sc, st, {}, max_depth, seed, flags, (uint32_t)(aa * aa) };
+	run.src.camera = true; run.src.cam = *camera; run.src.W = width; run.src.H = height; run.src.aa = aa;
+	run.src.tileRank = tile_rank; run.src.tileRanks = tile_ranks;
+	const uint64_t localPix = (uint64_t)localTiles(width, height, tile_rank, tile_ranks) * 256;
+	if (int rc = run.all(localPix * run.aaSq)) return rc;
+	rtk_resolve(st, sc->accum, width, height, tile_rank, tile_ranks, 0, (uint32_t)localPix, run.aaSq, 0, rgb_dev);
+	// the padding slots of partial edge tiles went through the first level as inactive lanes: they are not rays
+	run.stats.rays_nearest -= (localPix - (uint64_t)ownedPixels(width, height, tile_rank, tile_ranks)) * run.aaSq;
+	return finish(sc, st, run, stats);
+}
+
+int rt_render_host(rt_scene* sc, const rt_camera* camera, int width, int height, int aa, int max_depth, uint32_t seed, uint32_t flags,
+                   float* rgb_host, rt_stats* stats) {
+	if (!sc || !rgb_host || width <= 0 || height <= 0) { rt::set_error("rt_render_host: bad argument"); return RT_EINVAL; }
+	HIPCHK(hipSetDevice(sc->device));
+	DevBuf frame;
+	const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+	if (int rc = frame.alloc(bytes)) return rc;
+	if (int rc = rt_render(sc, camera, width, height, aa, max_depth, 0, 1, seed, flags, frame.as<float>(), nullptr, stats)) return rc;
+	HIPCHK(hipMemcpy(rgb_host, frame.p, bytes, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_trace_batch(rt_scene* sc, const float* e, const float* s, size_t n, int max_depth, uint32_t seed, uint32_t flags,
+                   uint8_t* hit, int32_t* obj_id, float* t, float* rgb, rt_stats* stats) {
+	if (!sc || !e || !s || max_depth < 0 || max_depth > 30 || n > (1ull << 31)) { rt::set_error("rt_trace_batch: bad argument"); return RT_EINVAL; }
+	if (stats) memset(stats, 0, sizeof *stats);
+	if (n == 0) return RT_OK;
+	HIPCHK(hipSetDevice(sc->device));
+	DevBuf de, ds, dhit, did, dt, drgb;
+	if (int rc = de.alloc(n * 12)) return rc;
+	if (int rc = ds.alloc(n * 12)) return rc;
+	if (int rc = dhit.alloc(n)) return rc;
+	if (int rc = did.alloc(n * 4)) return rc;
+	if (int rc = dt.alloc(n * 4)) return rc;
+	if (int rc = drgb.alloc(n * 12)) return rc;
+	HIPCHK(hipMemcpy(de.p, e, n * 12, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(ds.p, s, n * 12, hipMemcpyHostToDevice));
+	hipStream_t st = nullptr;
+	if (int rc = begin(sc, st, flags)) return rc;
+	if (int rc = sc->ensureAccum((uint32_t)n)) return rc;
+	Run run{ sc, st, {}, max_depth, seed, flags, 1u };
+	run.src.a = de.as<float>(); run.src.b = ds.as<float>();
+	run.src.outHit = dhit.as<uint8_t>(); run.src.outId = did.as<int32_t>(); run.src.outT = dt.as<float>();
+	if (int rc = run.all(n)) return rc;
+	rtk_resolve(st, sc->accum, 0, 0, 0, 1, 0, (uint32_t)n, 1, 1, drgb.as<float>());
+	if (int rc = finish(sc, st, run, stats)) return rc;
+	if (hit) HIPCHK(hipMemcpy(hit, dhit.p, n, hipMemcpyDeviceToHost));
+	if (obj_id) HIPCHK(hipMemcpy(obj_id, did.p, n * 4, hipMemcpyDeviceToHost));
+	if (t) HIPCHK(hipMemcpy(t, dt.p, n * 4, hipMemcpyDeviceToHost));
+	if (rgb) HIPCHK(hipMemcpy(rgb, drgb.p, n * 12, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_intersect_batch(rt_scene* sc, const float* e, const float* d, size_t n, uint32_t flags, uint8_t* hit, int32_t* obj_id, float* t, rt_stats* stats) {
+	if (!sc || !e || !d || n > (1ull << 31)) { rt::set_error("rt_intersect_batch: bad argument"); return RT_EINVAL; }
+	if (stats) memset(stats, 0, sizeof *stats);
+	if (n == 0) return RT_OK;
+	HIPCHK(hipSetDevice(sc->device));
+	DevBuf de, dd, dhit, did, dt;
+	if (int rc = de.alloc(n * 12)) return rc;
+	if (int rc = dd.alloc(n * 12)) return rc;
+	if (int rc = dhit.alloc(n)) return rc;
+	if (int rc = did.alloc(n * 4)) return rc;
+	if (int rc = dt.alloc(n * 4)) return rc;
+	HIPCHK(hipMemcpy(de.p, e, n * 12, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(dd.p, d, n * 12, hipMemcpyHostToDevice));
+	hipStream_t st = nullptr;
+	if (int rc = begin(sc, st, flags)) return rc;
+	Run run{ sc, st, {}, 0, 0, flags, 1u };
+	for (size_t c0 = 0; c0 < n; c0 += sc->qcap) {
+		const uint32_t cnt = (uint32_t)std::min<size_t>(sc->qcap, n - c0);
+		rtk_load_rays(st, de.as<float>() + 3 * c0, dd.as<float>() + 3 * c0, cnt, 0, sc->ray[0], 0);
+		rtk_intersect(st, sc->dev, sc->hasCsg, (flags & RT_FLAG_COUNTERS) != 0, sc->ray[0], cnt, sc->hitq, sc->ctr);
+		rtk_export_hits(st, sc->dev, sc->hitq, cnt, dhit.as<uint8_t>() + c0, did.as<int32_t>() + c0, dt.as<float>() + c0);
+		run.stats.rays_nearest += cnt;
+	}
+	run.stats.levels = 1;
+	if (int rc = finish(sc, st, run, stats)) return rc;
+	if (hit) HIPCHK(hipMemcpy(hit, dhit.p, n, hipMemcpyDeviceToHost));
+	if (obj_id) HIPCHK(hipMemcpy(obj_id, did.p, n * 4, hipMemcpyDeviceToHost));
+	if (t) HIPCHK(hipMemcpy(t, dt.p, n * 4, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_shadow_batch(rt_scene* sc, const float* point, const float* light_pos, size_t n, uint32_t flags, uint8_t* lit, float* shadow, rt_stats* stats) {
+	if (!sc || !point || !light_pos || n > (1ull << 31)) { rt::set_error("rt_shadow_batch: bad argument"); return RT_EINVAL; }
+	if (stats) memset(stats, 0, sizeof *stats);
+	if (n == 0) return RT_OK;
+	HIPCHK(hipSetDevice(sc->device));
+	DevBuf dp, dl, dlit, dsh;
+	if (int rc = dp.alloc(n * 12)) return rc;
+	if (int rc = dl.alloc(n * 12)) return rc;
+	if (int rc = dlit.alloc(n)) return rc;
+	if (int rc = dsh.alloc(n * 12)) return rc;
+	HIPCHK(hipMemcpy(dp.p, point, n * 12, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(dl.p, light_pos, n * 12, hipMemcpyHostToDevice));
+	hipStream_t st = nullptr;
+	if (int rc = begin(sc, st, flags)) return rc;
+	Run run{ sc, st, {}, 0, 0, flags & ~RT_FLAG_COUNTERS, 1u };
+	rtk_shadow_query(st, sc->dev, sc->hasCsg, dp.as<float>(), dl.as<float>(), (uint32_t)n, dlit.as<uint8_t>(), dsh.as<float>());
+	run.stats.rays_shadow = n;
+	if (int rc = finish(sc, st, run, stats)) return rc;
+	if (lit) HIPCHK(hipMemcpy(lit, dlit.p, n, hipMemcpyDeviceToHost));
+	if (shadow) HIPCHK(hipMemcpy(shadow, dsh.p, n * 12, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int64_t rt_tiles_count(int width, int height, int tile_rank, int tile_ranks) {
+	if (width <= 0 || height <= 0 || tile_ranks < 1 || tile_rank < 0 || tile_rank >= tile_ranks) return -1;
+	return localTiles(width, height, tile_rank, tile_ranks);
+}
+
+static int tilesCopy(rt_scene* sc, const float* src, float* dst, int width, int height, int tile_rank, int tile_ranks, void* stream, int mode) {
+	if (!sc || !src || !dst || rt_tiles_count(width, height, tile_rank, tile_ranks) < 0) { rt::set_error("rt_tiles_*: bad argument"); return RT_EINVAL; }
+	HIPCHK(hipSetDevice(sc->device));
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	rtk_tiles_copy(st, src, dst, width, height, tile_rank, tile_ranks, (uint32_t)(localTiles(width, height, tile_rank, tile_ranks) * 256), mode);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(st));
+	return RT_OK;
+}
+int rt_tiles_pack(rt_scene* sc, const float* frame_dev, float* packed_dev, int width, int height, int tile_rank, int tile_ranks, void* stream) {
+	return tilesCopy(sc, frame_dev, packed_dev, width, height, tile_rank, tile_ranks, stream, 0);
+}
+int rt_tiles_unpack(rt_scene* sc, const float* packed_dev, float* frame_dev, int width, int height, int tile_rank, int tile_ranks, void* stream) {
+	return tilesCopy(sc, packed_dev, frame_dev, width, height, tile_rank, tile_ranks, stream, 1);
+}
+int rt_tiles_merge(rt_scene* sc, const float* src_dev, float* dst_dev, int width, int height, int tile_rank, int tile_ranks, void* stream) {
+	return tilesCopy(sc, src_dev, dst_dev, width, height, tile_rank, tile_ranks, stream, 2);
+}
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+// rt_device.h -- device-side geometry and shading primitives for gfx950 (included only by rt_kernels.hip).
+//
+// Everything here is the per-lane arithmetic of the reference's hot path, re-expressed for a 64-wide wavefront:
+// no virtual dispatch, no per-object hit caches (the hit point is recomputed from (e, d, t) -- every rayhit() in
+// the reference sets cachedHitpoint = e + t*d), no heap.  Results must equal the reference's bit for bit wherever
+// they decide a hit, so the float/double mix and GLM's operation order are kept and the file is compiled with
+// -ffp-contract=off (no FMA contraction; hipcc's default correctly-rounded fp32 divide/sqrt).
+// Reference citations are relative to /root/reference/src.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rt_scene.h"
+
+namespace rtd {
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+// glm/detail/func_geometric.inl:54-60, 74-85, 14-19, 88-96
+__device__ __forceinline__ float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 x, f3 y) { return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+__device__ __forceinline__ float length(f3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+__device__ __forceinline__ bool isZero3(const float* v) { return v[0] == 0 && v[1] == 0 && v[2] == 0; }   // raymath.cpp:59-61
+
+#define RTD_PI 3.14159265358979323846264338327950288   /* objects.h:9 */
+
+// ---- counter-based replacement for rand() (same function as oracle/restate.cpp rng2) -------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__device__ __forceinline__ void rng2(uint32_t seed, uint32_t ray, uint32_t path, uint32_t light, uint32_t sample, float& u1, float& u2) {
+	uint32_t h = mix32(seed ^ 0x9e3779b9u);
+	h = mix32(h ^ ray);
+	h = mix32(h + path * 0x85ebca6bu);
+	h = mix32(h ^ (light * 0xc2b2ae35u + sample));
+	uint32_t a = mix32(h ^ 0x27d4eb2fu), b = mix32(h + 0x165667b1u);
+	u1 = (float)(a >> 8) * (1.0f / 16777216.0f);
+	u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+}
+
+// ---- BoundingBox::intersect, objects.cpp:11-44 --------------------------------------------------------
+// The reference leaves the axis loop early with -1; tnear only grows, tfar only shrinks and neither ever becomes
+// NaN (they are assigned under an ordered compare), so "tnear > tfar || tfar < 0" stays true once true and the
+// three axes can be evaluated unconditionally with the same outcome.  Returns -1 (miss), else tnear/tfar clamped
+// at 0 exactly as the reference does.
+__device__ __forceinline__ void slab(float mn, float mx, float e, float d, float& tnear, float& tfar, bool& miss) {
+	miss = miss || (d == 0 && (e < mn || e > mx));
+	float t1 = (mn - e) / d;
+	float t2 = (mx - e) / d;
+	if (t1 > t2) { float s = t1; t1 = t2; t2 = s; }
+	if (t1 > tnear) tnear = t1;
+	if (t2 < tfar) tfar = t2;
+	miss = miss || (tnear > tfar) || (tfar < 0);
+}
+__device__ __forceinline__ float boxIntersect(const float* b, f3 e, f3 d, bool exitHit) {
+	float tnear = -RT_MAX_T, tfar = RT_MAX_T;
+	bool miss = false;
+	slab(b[0], b[1], e.x, d.x, tnear, tfar, miss);
+	slab(b[2], b[3], e.y, d.y, tnear, tfar, miss);
+	slab(b[4], b[5], e.z, d.z, tnear, tfar, miss);
+	if (miss) return -1.0f;
+	if (!exitHit) return tnear < 0 ? 0.0f : tnear;
+	return tfar < 0 ? 0.0f : tfar;
+}
+
+// ---- Sphere::rayhit, objects.cpp:159-178 (fp64 island kept op for op; pow(x,2) in double is exactly x*x) ----
+__device__ __forceinline__ float sphereHit(f3 center, float radius, f3 e, f3 d, bool exitHit) {
+	f3 ec = e - center;
+	float dde = dot(d, ec);
+	float dd = dot(d, d);
+	double disc = (double)dde * (double)dde - (double)(dd * (dot(ec, ec) - radius * radius));
+	if (disc < 0) return 0.0f;
+	double rest = (double)(dot(-d, ec) / dd);
+	double q = sqrt(disc) / (double)dd;
+	double t = exitHit ? rest + q : rest - q;
+	if (t < 0) return 0.0f;
+	return (float)t;
+}
+
+// ---- Plane::rayhit, objects.cpp:199-213 ----
+__device__ __forceinline__ float planeHit(f3 point, f3 normal, f3 e, f3 d, bool exitHit) {
+	f3 n = exitHit ? -normal : normal;
+	double numerator = (double)dot(n, point - e);
+	double denominator = (double)dot(n, d);
+	double t = numerator / denominator;
+	if (t <= 0 || numerator > 0) return 0.0f;
+	return (float)t;
+}
+
+// ---- Triangle::rayhit objects.cpp:251-261 + pointInTriangle raymath.cpp:26-32 ----
+__device__ __forceinline__ float triHit(f3 p0, f3 p1, f3 p2, f3 n, f3 e, f3 d, bool exitHit) {
+	float t = planeHit(p0, n, e, d, exitHit);
+	f3 hitpos = e + t * d;
+	float test1 = dot(cross(hitpos - p0, p1 - p0), n);
+	float test2 = dot(cross(hitpos - p1, p2 - p1), n);
+	float test3 = dot(cross(hitpos - p2, p0 - p2), n);
+	bool inside = (test1 >= 0 && test2 >= 0 && test3 >= 0) || (test1 <= 0 && test2 <= 0 && test3 <= 0);
+	if (t <= 0 || !inside) return 0.0f;
+	return t;
+}
+__device__ __forceinline__ float triHit(const rt_tri* tr, f3 e, f3 d, bool exitHit) {
+	// 64 B record: four 16 B loads
+	const float4* q = reinterpret_cast<const float4*>(tr);
+	float4 a = q[0], b = q[1], c = q[2];
+	return triHit(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), e, d, exitHit);
+}
+
+// ---- Box::rayhit objects.cpp:337-346 / Box::getNormal :348-361 ----
+__device__ __forceinline__ float boxHit(const float* b, f3 e, f3 d, bool exitHit) {
+	float t = boxIntersect(b, e, d, exitHit);
+	return t < 0 ? 0.0f : t;
+}
+__device__ __forceinline__ void boxNormal(const float* b, f3 hp, f3& n) {   // n is left untouched when no face matches
+	if ((double)fabsf(hp.x - b[0]) < 1e-5) n = mk3(-1, 0, 0);
+	else if ((double)fabsf(hp.x - b[1]) < 1e-5) n = mk3(1, 0, 0);
+	else if ((double)fabsf(hp.y - b[2]) < 1e-5) n = mk3(0, -1, 0);
+	else if ((double)fabsf(hp.y - b[3]) < 1e-5) n = mk3(0, 1, 0);
+	else if ((double)fabsf(hp.z - b[4]) < 1e-5) n = mk3(0, 0, -1);
+	else if ((double)fabsf(hp.z - b[5]) < 1e-5) n = mk3(0, 0, 1);
+}
+
+// Everything a kernel needs to know about the scene; passed by value (kernel arguments), pointers are HBM.
+struct DevScene {
+	const rt_plane* planes;
+	const rt_sphere* spheres;
+	const rt_tri* tris;
+	const rt_box* boxes;
+	const rt_csg* csgs;
+	const rt_csg_node* csg_nodes;
+	const rt_mesh* meshes;
+	const rt_tri* mesh_tris;
+	const rt_uv* uvs;
+	const rt_material* materials;
+	const rt_light* lights;
+	const rt_texture* textures;
+	const uint8_t* texels;
+	const rt_bvh_node* nodes;
+	const uint32_t* leaf_prims;
+	int32_t n_planes, n_lights;
+	int32_t root_child, root_count;
+	float root_box[6];
+	float background[3];
+};
+
+// ---- Mesh::rayhit, objects.cpp:286-304 (linear scan in scene order; first of equal t wins) ----
+__device__ inline float meshHit(const DevScene& S, const rt_mesh& m, f3 e, f3 d, bool exitHit, f3& nrm) {
+	float t_min = RT_MAX_T;
+	for (int i = 0; i < m.tri_count; i++) {
+		const rt_tri* tr = S.mesh_tris + m.tri_first + i;
+		float t = triHit(tr, e, d, exitHit);
+		if (t > 0.0f && t < t_min) { nrm = ld3(tr->n); t_min = t; }
+	}
+	return t_min == RT_MAX_T ? 0.0f : t_min;
+}
+
+// ---- CSG: csg_node::setIntervals csg.cpp:95-232, csgObject::rayhit csg.cpp:8-26 ------------------------------
+// An interval boundary carries its t and, instead of the normal itself, a TAG saying where the normal comes from:
+// bits 0-7 node index inside the object's program, bit 8 = the leaf's far (exit) hit, bit 9 = negated an odd
+// number of times by Difference (csg.cpp:211-212).  The winning boundary's normal is recomputed from its tag, which
+// repeats the leaf's own computation and is therefore identical.
+struct CsgB { float t; uint32_t tag; };
+struct CsgIv { CsgB a, b; };
+#define RTD_CSG_CAP (2 * RT_MAX_CSG_LEAVES)   /* intervals alive over the whole evaluation stack */
+
+__device__ __forceinline__ CsgB csgMaxB(CsgB x, CsgB y) { return (x.t < y.t) ? y : x; }   // std::max(a,b,cmp): a unless a<b
+__device__ __forceinline__ CsgB csgMinB(CsgB x, CsgB y) { return (y.t < x.t) ? y : x; }   // std::min(a,b,cmp): a unless b<a
+
+__device__ inline float csgLeafHit(const DevScene& S, const rt_csg_node& nd, f3 e, f3 d, bool exitHit, f3* nrm) {
+	if (nd.kind == RT_CSG_SPHERE) {
+		f3 c = mk3(nd.f[0], nd.f[1], nd.f[2]);
+		float t = sphereHit(c, nd.f[3], e, d, exitHit);
+		if (nrm) *nrm = normalize((e + t * d) - c);   // Sphere::getNormal, objects.cpp:180-182 (only used when t > 0)
+		return t;
+	}
+	if (nd.kind == RT_CSG_BOX) {
+		float t = boxHit(nd.f, e, d, exitHit);
+		if (nrm) { f3 n = mk3(0, 0, 0); boxNormal(nd.f, e + t * d, n); *nrm = n; }
+		return t;
+	}
+	f3 n = mk3(0, 0, 0);
+	float t = meshHit(S, S.meshes[nd.mesh], e, d, exitHit, n);
+	if (nrm) *nrm = n;
+	return t;
+}
+
+// Evaluates the object's post-order program for one ray; returns csgObject::rayhit's t (0 = no hit) and the tag of
+// the selected boundary.
+__device__ inline float csgEval(const DevScene& S, const rt_csg& c, f3 e, f3 d, bool exitHit, uint32_t& tagOut) {
+	CsgIv arena[RTD_CSG_CAP];
+	CsgIv tmp[RTD_CSG_CAP];
+	int start[RT_MAX_CSG_LEAVES + 1];   // start[k] = arena offset of list k on the evaluation stack; start[sp] = end
+	int sp = 0;
+	start[0] = 0;
+	for (int k = 0; k < c.node_count; k++) {
+		const rt_csg_node& nd = S.csg_nodes[c.node_first + k];
+		if (nd.kind >= RT_CSG_SPHERE) {   // leaf, csg.cpp:99-111
+			int at = start[sp];
+			float tn = csgLeafHit(S, nd, e, d, false, nullptr);
+			float tf = csgLeafHit(S, nd, e, d, true, nullptr);
+			int n = 0;
+			if (tf > 0 && at < RTD_CSG_CAP && sp < RT_MAX_CSG_LEAVES) {
+				arena[at].a.t = tn; arena[at].a.tag = (uint32_t)k;
+				arena[at].b.t = tf; arena[at].b.tag = (uint32_t)k | 0x100u;
+				n = 1;
+			}
+			if (sp < RT_MAX_CSG_LEAVES) { sp++; start[sp] = at + n; }
+			continue;
+		}
+		if (sp < 2) continue;   // malformed program (rejected at upload); keeps the indices in range regardless
+		const int a0 = start[sp - 2], a1 = start[sp - 1], b1 = start[sp];
+		const CsgIv* l1 = arena + a0; const int n1 = a1 - a0;
+		const CsgIv* l2 = arena + a1; const int n2 = b1 - a1;
+		int n = 0;
+		if (nd.kind == RT_CSG_UNION) {   // csg.cpp:123-188
+			if (n1 == 0) { for (int i = 0; i < n2; i++) tmp[n++] = l2[i]; }
+			else if (n2 == 0) { for (int i = 0; i < n1; i++) tmp[n++] = l1[i]; }
+			else {
+				int c1 = 0, c2 = 0;
+				CsgIv cur;
+				if (l1[0].a.t < l2[0].a.t) cur = l1[c1++]; else cur = l2[c2++];
+				while (c1 < n1 || c2 < n2) {
+					CsgIv add;
+					if (c1 < n1 && c2 < n2) { if (l1[c1].a.t < l2[c2].a.t) add = l1[c1++]; else add = l2[c2++]; }
+					else if (c1 < n1) add = l1[c1++];
+					else add = l2[c2++];
+					if (add.a.t < cur.b.t) cur.b = csgMaxB(cur.b, add.b);
+					else { if (n < RTD_CSG_CAP) tmp[n++] = cur; cur = add; }
+				}
+				if (n < RTD_CSG_CAP) tmp[n++] = cur;
+			}
+		} else if (nd.kind == RT_CSG_INTERSECTION) {   // csg.cpp:190-200
+			for (int c1 = 0; c1 < n1; c1++)
+				for (int c2 = 0; c2 < n2; c2++)
+					if (l1[c1].a.t < l2[c2].b.t && l1[c1].b.t > l2[c2].a.t && n < RTD_CSG_CAP) {
+						tmp[n].a = csgMaxB(l1[c1].a, l2[c2].a);
+						tmp[n].b = csgMinB(l1[c1].b, l2[c2].b);
+						n++;
+					}
+			// std::sort by entry t; for <= 16 elements libstdc++ runs a plain (stable) insertion sort
+			for (int i = 1; i < n; i++) {
+				CsgIv v = tmp[i];
+				int j = i;
+				while (j > 0 && v.a.t < tmp[j - 1].a.t) { tmp[j] = tmp[j - 1]; j--; }
+				tmp[j] = v;
+			}
+		} else {   // Difference, csg.cpp:202-230
+			for (int c1 = 0; c1 < n1; c1++) {
+				CsgB cur = l1[c1].a;
+				for (int c2 = 0; c2 < n2 && cur.t < l1[c1].b.t; c2++) {
+					CsgIv sub = l2[c2];
+					sub.a.tag ^= 0x200u; sub.b.tag ^= 0x200u;
+					if (l1[c1].a.t < sub.b.t && l1[c1].b.t > sub.a.t) {
+						if (sub.a.t < cur.t) cur = sub.b;
+						else {
+							if (n < RTD_CSG_CAP) { tmp[n].a = cur; tmp[n].b = sub.a; n++; }
+							cur = sub.b;
+						}
+					}
+				}
+				if (cur.t < l1[c1].b.t && n < RTD_CSG_CAP) { tmp[n].a = cur; tmp[n].b = l1[c1].b; n++; }
+			}
+		}
+		if (a0 + n > RTD_CSG_CAP) n = RTD_CSG_CAP - a0;
+		for (int i = 0; i < n; i++) arena[a0 + i] = tmp[i];
+		sp--;
+		start[sp] = a0 + n;
+	}
+	float t = 0;
+	tagOut = 0;
+	if (sp >= 1) {
+		const int a0 = start[sp - 1], a1 = start[sp];
+		for (int i = a0; i < a1 && t == 0; i++) {   // csg.cpp:13-22
+			if (!exitHit && arena[i].a.t > 0) { t = arena[i].a.t; tagOut = arena[i].a.tag; }
+			else if (exitHit && arena[i].b.t > 0) { t = arena[i].b.t; tagOut = arena[i].b.tag; }
+		}
+	}
+	return t;
+}
+
+// The normal csgObject::getNormal would return (cachedHitNormal) for the boundary `tag` of the ray (e, d).
+__device__ inline f3 csgNormal(const DevScene& S, const rt_csg& c, f3 e, f3 d, uint32_t tag) {
+	const rt_csg_node& nd = S.csg_nodes[c.node_first + (int)(tag & 0xffu)];
+	f3 n;
+	csgLeafHit(S, nd, e, d, (tag & 0x100u) != 0, &n);
+	return (tag & 0x200u) ? -n : n;
+}
+
+// EasyBMP BMP::operator()(i,j): both indices clamped (EasyBMP.cpp:310-329)
+__device__ __forceinline__ const uint8_t* texel(const DevScene& S, int tex, int i, int j) {
+	const rt_texture T = S.textures[tex];
+	if (i >= T.width) i = T.width - 1;
+	if (i < 0) i = 0;
+	if (j >= T.height) j = T.height - 1;
+	if (j < 0) j = 0;
+	return S.texels + T.offset + 3 * ((int64_t)j * T.width + i);
+}
+
+// float -> int the way x86 cvttss2si does it for out-of-range / NaN inputs (INT_MIN), so that int(u*width) in
+// bump.cpp:21 / texturemesh.cpp:12 agrees with the oracle even for garbage coordinates
+__device__ __forceinline__ int f2i(float v) {
+	if (!(v > -2147483648.0f && v < 2147483648.0f)) return (int)0x80000000;
+	return (int)v;
+}
+
+// Sphere::getNormal objects.cpp:180-182 / BumpSphere::getNormal bump.cpp:8-34
+__device__ inline f3 sphereNormal(const DevScene& S, const rt_sphere& s, f3 hp) {
+	f3 trueNormal = normalize(hp - ld3(s.center));
+	if (s.bump_tex < 0) return trueNormal;
+	float u = (float)(0.5 - (double)atan2f(-trueNormal.z, -trueNormal.x) / (2 * RTD_PI));
+	float v = (float)(0.5 - (double)asinf(trueNormal.y) / RTD_PI);
+	const int height = S.textures[s.bump_tex].height, width = S.textures[s.bump_tex].width;
+	float value = float(texel(S, s.bump_tex, f2i(u * width), f2i(v * height))[0]) / 255;
+	float value_u = float(texel(S, s.bump_tex, f2i(u * width + 1) % width, f2i(v * height))[0]) / 255;
+	float value_v = float(texel(S, s.bump_tex, f2i(u * width), f2i(v * height + 1) % height)[0]) / 255;
+	float gradient_u = value_u - value;
+	float gradient_v = value_v - value;
+	f3 tangent_u = normalize(cross(mk3(0, 1, 0), trueNormal));
+	f3 tangent_v = normalize(cross(trueNormal, tangent_u));
+	return normalize(trueNormal + gradient_u * s.bump_depth * tangent_u + gradient_v * s.bump_depth * tangent_v);
+}
+
+// ---- raymath.cpp:3-24 ----
+__device__ __forceinline__ bool refractRay(f3 Vi, f3 N, float refraction, f3& Vr) {
+	float VidotN = dot(Vi, N);
+	float refratio = (float)(1.0 / (double)refraction);
+	f3 n = N;
+	if (VidotN < 0) VidotN = -VidotN;
+	else { refratio = (float)(1.0 / (double)refratio); n = -N; }
+	float k = (float)(1 - ((double)refratio * (double)refratio) * (1 - (double)VidotN * (double)VidotN));
+	if (k < 0) return false;
+	Vr = normalize(refratio * Vi + (refratio * VidotN - sqrtf(k)) * n);
+	return true;
+}
+__device__ __forceinline__ f3 reflectRay(f3 V, f3 N) { return normalize(2 * dot(N, V) * N - V); }
+
+// ---- raymath.cpp:34-57: the two Phong terms for unit light colour I ----
+__device__ __forceinline__ f3 phong(f3 I, const float* kd, const float* ks, float shininess, f3 N, f3 L, f3 V) {
+	f3 colour = mk3(0, 0, 0);
+	f3 diffuse = I * ld3(kd) * dot(N, L);
+	if (diffuse.x < 0) diffuse.x = 0;
+	if (diffuse.y < 0) diffuse.y = 0;
+	if (diffuse.z < 0) diffuse.z = 0;
+	colour = colour + diffuse;
+	f3 R = normalize(2 * (dot(N, L)) * N - L);
+	float RdotV = dot(R, V);
+	if (RdotV > 0) {
+		f3 specular = I * ld3(ks) * powf(RdotV, shininess);
+		if (specular.x < 0) specular.x = 0;
+		if (specular.y < 0) specular.y = 0;
+		if (specular.z < 0) specular.z = 0;
+		colour = colour + specular;
+	}
+	return colour;
+}
+
+}  // namespace rtd

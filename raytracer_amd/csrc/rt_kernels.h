@@ -1,0 +1,46 @@
+// rt_kernels.h -- what rt_capi_device.hip (host orchestration) and rt_kernels.hip (device code) share.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rt_scene.h"
+#include "rt_device.h"
+
+#define RT_BLOCK 256          /* threads per workgroup = 4 wavefronts */
+#define RT_STACK_DEPTH 20     /* per-lane traversal stack entries in LDS (20 x 256 x 4 B = 20 KB per workgroup);
+                                 a nearer-child-first walk of a binary tree needs at most its depth, and the
+                                 reference's build stops at depth 16 (bvh.h:6); checked at upload */
+
+// SoA queue: component c of slot i lives at f[c * cap + i]
+struct RtQueue { float* f; uint32_t cap; };
+enum { RQ_OX, RQ_OY, RQ_OZ, RQ_DX, RQ_DY, RQ_DZ, RQ_WR, RQ_WG, RQ_WB, RQ_PIX, RQ_PATH, RQ_COMPS };   // ray: origin, direction (unnormalised), RGB weight, pixel key, tree position
+enum { HQ_PRIM, HQ_T, HQ_TAG, HQ_COMPS };                                                             // hit: primitive reference, t, csg boundary tag
+enum { SQ_PX, SQ_PY, SQ_PZ, SQ_NX, SQ_NY, SQ_NZ, SQ_VX, SQ_VY, SQ_VZ, SQ_KDR, SQ_KDG, SQ_KDB, SQ_KSR, SQ_KSG, SQ_KSB,
+       SQ_SHIN, SQ_WR, SQ_WG, SQ_WB, SQ_PIX, SQ_PATH, SQ_COMPS };                                     // surface: what the light loop needs (p, N, V, kd, ks, shininess, weight)
+
+struct RtCounters {
+	uint32_t next_count;      // rays appended to the next level's queue
+	uint32_t surf_count;      // surface records appended
+	uint32_t overflow;        // an append found its queue full (the batch is re-run in halves)
+	uint32_t pad;
+	unsigned long long nodes; // RT_FLAG_COUNTERS
+	unsigned long long prims;
+};
+
+// 32.32 fixed-point accumulators: three planes of npix, plus a per-pixel "saw a NaN/inf" byte
+struct RtAccum { unsigned long long* rgb; uint8_t* nonfinite; uint32_t npix; };
+
+using rtd::DevScene;
+
+void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aa, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq);
+void rtk_load_rays(hipStream_t st, const float* a, const float* b, uint32_t n, int bIsTarget, RtQueue rq, uint32_t pixBase);
+void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr);
+void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, uint8_t* hit, int32_t* id, float* t);
+void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtCounters* ctr, RtAccum A,
+               uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT);
+void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
+                      RtAccum A, uint32_t aaSq, RtCounters* ctr);
+void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t samples, uint32_t seed,
+                     RtAccum A, uint32_t aaSq, RtCounters* ctr);
+void rtk_shadow_query(hipStream_t st, const DevScene& S, bool csg, const float* point, const float* lightPos, uint32_t n, uint8_t* lit, float* shadow);
+void rtk_resolve(hipStream_t st, RtAccum A, int W, int H, int tileRank, int tileRanks, uint32_t lp0, uint32_t count, uint32_t aaSq, int linear, float* rgb);
+void rtk_tiles_copy(hipStream_t st, const float* src, float* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode);

@@ -1,0 +1,705 @@
+// rt_kernels.hip -- the wavefront pipeline for gfx950 (MI355X): generate -> [intersect -> shade -> shadow]* -> resolve.
+//
+// The reference evaluates one pixel at a time by mutual recursion (trace -> findNearest -> lightPoint -> trace /
+// shadowRay).  Here one LEVEL of the ray tree of a whole batch of pixels is processed per
+// iteration: rays live in SoA queues in HBM (component c of slot i at base[c*cap + i], so a wave's 64 lanes read
+// 256 contiguous bytes per component), child rays are appended to the next level's queue through one atomic per
+// wave (ballot + prefix popcount), and the recursion's colour arithmetic becomes a per-ray RGB weight: the
+// reference's combine  C = (1-kt)*(kr*C_refl + sum lights) + kt*C_trans  (objects.cpp:60-104) is linear in the
+// child colours.  Pixel sums are accumulated in 32.32 fixed point with integer atomics, which is associative, so
+// the image does not depend on the order in which waves retire.
+//
+// Kernels (all 256-thread blocks = 4 waves):
+//   k_generate      q1.cpp:51-64 primary rays, in 8x8-pixel blocks per wave inside 32x8 tiles
+//   k_intersect     BVH::findNearest bvh.cpp:72-121; per-lane traversal stack in LDS, nearer child first
+//   k_shade         Object::lightPoint objects.cpp:54-105 minus the shadow rays: normals (bump.cpp), textures
+//                   (texturemesh.cpp), ambient term, reflection / transmission children (transmitRay)
+//   k_shadow_point  Directional/Point/Spot::lightPoint objects.cpp:399-458 -> BVH::calcShadow bvh.cpp:123-160
+//   k_shadow_area   AreaLight::lightPoint arealight.cpp:7-22, one lane per sample, segmented wave reduction
+//   k_resolve       fixed point -> float RGB (+ the /4 of q1.cpp:140 for supersampling)
+#include "rt_kernels.h"
+#include "rt_device.h"
+
+using namespace rtd;
+
+namespace {
+
+constexpr int kBlock = RT_BLOCK;
+constexpr int kStack = RT_STACK_DEPTH;
+constexpr uint32_t kInactive = 0xffffffffu;
+
+__device__ __forceinline__ float qf(const RtQueue& q, int comp, uint32_t i) { return q.f[(size_t)comp * q.cap + i]; }
+__device__ __forceinline__ uint32_t qu(const RtQueue& q, int comp, uint32_t i) { return __float_as_uint(q.f[(size_t)comp * q.cap + i]); }
+__device__ __forceinline__ void qsf(const RtQueue& q, int comp, uint32_t i, float v) { q.f[(size_t)comp * q.cap + i] = v; }
+__device__ __forceinline__ void qsu(const RtQueue& q, int comp, uint32_t i, uint32_t v) { q.f[(size_t)comp * q.cap + i] = __uint_as_float(v); }
+
+// One slot per lane with the predicate set, one atomic per wave.  Must be reached by every lane of the wave.
+__device__ __forceinline__ uint32_t wavePush(bool pred, uint32_t* counter) {
+	const unsigned long long mask = __ballot(pred);
+	if (mask == 0) return kInactive;
+	const uint32_t lane = __lane_id();
+	const int leader = __ffsll((long long)mask) - 1;
+	uint32_t base = 0;
+	if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+	base = __shfl(base, leader);
+	return pred ? base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)) : kInactive;
+}
+
+// 32.32 fixed-point accumulation (associative => order-independent image)
+__device__ __forceinline__ void accumChannel(unsigned long long* plane, uint32_t pixel, float c) {
+	if (c == 0.0f) return;
+	double v = (double)c * 4294967296.0;
+	if (v > 4.0e18) v = 4.0e18;
+	if (v < -4.0e18) v = -4.0e18;
+	atomicAdd(plane + pixel, (unsigned long long)__double2ll_rn(v));
+}
+__device__ __forceinline__ void accumAdd(const RtAccum& A, uint32_t pixel, f3 c) {
+	if (!(isfinite(c.x) && isfinite(c.y) && isfinite(c.z))) { A.nonfinite[pixel] = 1; return; }
+	accumChannel(A.rgb, pixel, c.x);
+	accumChannel(A.rgb + A.npix, pixel, c.y);
+	accumChannel(A.rgb + 2 * (size_t)A.npix, pixel, c.z);
+}
+
+// local pixel number (tile-major, 8x8 blocks inside a 32x8 tile) -> image coordinates
+__device__ __forceinline__ bool tilePixel(uint32_t lp, int W, int H, int rank, int ranks, int& x, int& y) {
+	const uint32_t tilesX = (uint32_t)(W + 31) / 32, tilesY = (uint32_t)(H + 7) / 8;
+	const unsigned long long gt = (unsigned long long)(lp >> 8) * (uint32_t)ranks + (uint32_t)rank;
+	if (gt >= (unsigned long long)tilesX * tilesY) return false;
+	const uint32_t tx = (uint32_t)(gt % tilesX), ty = (uint32_t)(gt / tilesX);
+	const uint32_t within = lp & 255u, sub = within >> 6, l = within & 63u;
+	x = (int)(tx * 32 + sub * 8 + (l & 7u));
+	y = (int)(ty * 8 + (l >> 3));
+	return x < W && y < H;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// primitive dispatch for BVH leaves: object->rayhit(e, d)  (bvh.cpp:112,148)
+// ---------------------------------------------------------------------------------------------------------
+template <bool CSG>
+__device__ __forceinline__ float primHit(const DevScene& S, uint32_t ref, f3 e, f3 d, uint32_t& tag) {
+	const uint32_t ix = RT_PRIM_INDEX(ref);
+	const uint32_t ty = RT_PRIM_TYPE(ref);
+	if (ty == RT_PRIM_TRI) return triHit(S.tris + ix, e, d, false);
+	if (ty == RT_PRIM_SPHERE) {
+		const float4 s = *reinterpret_cast<const float4*>(S.spheres + ix);
+		return sphereHit(mk3(s.x, s.y, s.z), s.w, e, d, false);
+	}
+	if (ty == RT_PRIM_BOX) {
+		const float4 a = *reinterpret_cast<const float4*>(S.boxes + ix);
+		const float2 b = *reinterpret_cast<const float2*>(S.boxes[ix].b + 4);
+		const float bb[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
+		return boxHit(bb, e, d, false);
+	}
+	if (CSG) return csgEval(S, S.csgs[ix], e, d, false, tag);
+	return 0.0f;
+}
+__device__ __forceinline__ int primMaterial(const DevScene& S, uint32_t ref) {
+	const uint32_t ix = RT_PRIM_INDEX(ref);
+	switch (RT_PRIM_TYPE(ref)) {
+	case RT_PRIM_SPHERE: return S.spheres[ix].mat;
+	case RT_PRIM_TRI: return S.tris[ix].mat;
+	case RT_PRIM_BOX: return S.boxes[ix].mat;
+	case RT_PRIM_CSG: return S.csgs[ix].mat;
+	case RT_PRIM_PLANE: return S.planes[ix].mat;
+	}
+	return 0;
+}
+__device__ __forceinline__ int primId(const DevScene& S, uint32_t ref) {
+	const uint32_t ix = RT_PRIM_INDEX(ref);
+	switch (RT_PRIM_TYPE(ref)) {
+	case RT_PRIM_SPHERE: return S.spheres[ix].id;
+	case RT_PRIM_TRI: return S.tris[ix].id;
+	case RT_PRIM_BOX: return S.boxes[ix].id;
+	case RT_PRIM_CSG: return S.csgs[ix].id;
+	case RT_PRIM_PLANE: return S.planes[ix].id;
+	}
+	return -1;
+}
+
+struct NodeRegs { float b0[6], b1[6]; int32_t c0, c1, n0, n1; };
+__device__ __forceinline__ NodeRegs loadNode(const rt_bvh_node* n) {   // one 64 B record = 4 x 16 B loads
+	const float4* q = reinterpret_cast<const float4*>(n);
+	const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+	NodeRegs r;
+	r.b0[0] = a.x; r.b0[1] = a.y; r.b0[2] = a.z; r.b0[3] = a.w; r.b0[4] = b.x; r.b0[5] = b.y;
+	r.b1[0] = b.z; r.b1[1] = b.w; r.b1[2] = c.x; r.b1[3] = c.y; r.b1[4] = c.z; r.b1[5] = c.w;
+	r.c0 = __float_as_int(d.x); r.c1 = __float_as_int(d.y); r.n0 = __float_as_int(d.z); r.n1 = __float_as_int(d.w);
+	return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BVH::findNearest (bvh.cpp:72-92) + findRecursive (bvh.cpp:94-121)
+//
+// The reference walks left-then-right and keeps the FIRST of equal-t hits (strict <).  This walk visits the nearer
+// child first, which prunes far more, and reproduces the reference's winner by breaking t ties with the
+// primitive's position in the reference's DFS leaf order (key = index into leaf_prims + 1; planes, which the
+// reference tests before the tree, have key 0).
+// ---------------------------------------------------------------------------------------------------------
+struct NearestResult { uint32_t prim; float t; uint32_t tag; };
+
+template <bool CSG, bool COUNT>
+__device__ __forceinline__ NearestResult nearestTraverse(const DevScene& S, int32_t (*stack)[kBlock], f3 e, f3 d, unsigned long long& cntNodes, unsigned long long& cntPrims) {
+	const int tid = threadIdx.x;
+	float tmin = RT_MAX_T;   // bvh.cpp:73
+	NearestResult best;
+	best.prim = RT_NO_HIT; best.t = 0; best.tag = 0;
+	uint32_t bestKey = 0;
+
+	for (int i = 0; i < S.n_planes; i++) {   // bvh.cpp:77-86
+		const float4 a = *reinterpret_cast<const float4*>(S.planes + i);
+		const float2 b = *reinterpret_cast<const float2*>(S.planes[i].normal + 1);
+		const float t = planeHit(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), e, d, false);
+		if (t > 0 && t < tmin) { best.prim = RT_PRIM_REF(RT_PRIM_PLANE, i); tmin = t; }
+	}
+
+	auto testLeaf = [&](int32_t first, int32_t count) {   // bvh.cpp:109-118
+		for (int k = 0; k < count; k++) {
+			const uint32_t ref = S.leaf_prims[first + k];
+			uint32_t tag = 0;
+			const float t = primHit<CSG>(S, ref, e, d, tag);
+			if (COUNT) cntPrims++;
+			const uint32_t key = (uint32_t)(first + k) + 1u;
+			if ((double)t > 1e-5 && (t < tmin || (t == tmin && key < bestKey))) { best.prim = ref; best.tag = tag; tmin = t; bestKey = key; }
+		}
+	};
+
+	if (!(S.root_child < 0 && S.root_count == 0)) {
+		const float tr = boxIntersect(S.root_box, e, d, false);   // bvh.cpp:97-100 at the root
+		if (!(tr < 0 || tr > tmin)) {
+			if (S.root_child < 0) testLeaf(~S.root_child, S.root_count);
+			else {
+				int sp = 0;
+				int32_t node = S.root_child;
+				while (true) {
+					const NodeRegs N = loadNode(S.nodes + node);
+					if (COUNT) cntNodes++;
+					const float t0 = boxIntersect(N.b0, e, d, false);
+					const float t1 = boxIntersect(N.b1, e, d, false);
+					bool h0 = !(t0 < 0 || t0 > tmin);
+					bool h1 = !(t1 < 0 || t1 > tmin);
+#pragma unroll 1
+					for (int c = 0; c < 2; c++) {   // leaf children are tested on the spot (tmin may shrink in between)
+						const int32_t child = c ? N.c1 : N.c0;
+						const float tb = c ? t1 : t0;
+						if ((c ? h1 : h0) && child < 0 && !(tb > tmin)) testLeaf(~child, c ? N.n1 : N.n0);
+					}
+					h0 = h0 && N.c0 >= 0 && !(t0 > tmin);
+					h1 = h1 && N.c1 >= 0 && !(t1 > tmin);
+					if (h0 && h1) {
+						const bool swap = t1 < t0;
+						if (sp < kStack) stack[sp++][tid] = swap ? N.c0 : N.c1;
+						node = swap ? N.c1 : N.c0;
+					} else if (h0) node = N.c0;
+					else if (h1) node = N.c1;
+					else {
+						if (sp == 0) break;
+						node = stack[--sp][tid];
+					}
+				}
+			}
+		}
+	}
+	best.t = best.prim == RT_NO_HIT ? 0.0f : tmin;
+	return best;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BVH::calcShadow (bvh.cpp:123-126) + shadowRecursive (bvh.cpp:128-160): any-hit with coloured attenuation.
+// Visiting order is free here (an opaque occluder ends the query whatever came before; the attenuation product
+// commutes), so both children are simply pushed.  Planes are not in the tree and never occlude.
+// ---------------------------------------------------------------------------------------------------------
+template <bool CSG, bool COUNT>
+__device__ __forceinline__ bool shadowTraverse(const DevScene& S, int32_t (*stack)[kBlock], f3 e, f3 d, f3& shadow, unsigned long long& cntNodes, unsigned long long& cntPrims) {
+	const int tid = threadIdx.x;
+	if (S.root_child < 0 && S.root_count == 0) return true;
+	const float len = length(d);
+	bool lit = true;
+
+	auto testLeaf = [&](int32_t first, int32_t count) {   // bvh.cpp:145-157
+		for (int k = 0; k < count && lit; k++) {
+			const uint32_t ref = S.leaf_prims[first + k];
+			uint32_t tag = 0;
+			const float t = primHit<CSG>(S, ref, e, d, tag);
+			if (COUNT) cntPrims++;
+			if (t < 1.0f && (double)(t * len) > 1e-5) {
+				const float* kt = S.materials[primMaterial(S, ref)].transmissive;
+				if (!isZero3(kt)) shadow = shadow * ld3(kt);
+				else lit = false;
+			}
+		}
+	};
+
+	const float tr = boxIntersect(S.root_box, e, d, false);
+	if (tr < 0 || tr > 1) return true;   // bvh.cpp:133-134
+	if (S.root_child < 0) { testLeaf(~S.root_child, S.root_count); return lit; }
+	int sp = 0;
+	int32_t node = S.root_child;
+	while (true) {
+		const NodeRegs N = loadNode(S.nodes + node);
+		if (COUNT) cntNodes++;
+		const float t0 = boxIntersect(N.b0, e, d, false);
+		const float t1 = boxIntersect(N.b1, e, d, false);
+		bool h0 = !(t0 < 0 || t0 > 1);
+		bool h1 = !(t1 < 0 || t1 > 1);
+#pragma unroll 1
+		for (int c = 0; c < 2; c++) {
+			const int32_t child = c ? N.c1 : N.c0;
+			if ((c ? h1 : h0) && child < 0 && lit) testLeaf(~child, c ? N.n1 : N.n0);
+		}
+		if (!lit) break;
+		h0 = h0 && N.c0 >= 0;
+		h1 = h1 && N.c1 >= 0;
+		if (h0 && h1) { if (sp < kStack) stack[sp++][tid] = N.c1; node = N.c0; }
+		else if (h0) node = N.c0;
+		else if (h1) node = N.c1;
+		else {
+			if (sp == 0) break;
+			node = stack[--sp][tid];
+		}
+	}
+	return lit;
+}
+
+// =========================================================================================================
+// kernels
+// =========================================================================================================
+
+__global__ __launch_bounds__(kBlock) void k_generate(rt_camera cam, int W, int H, int aa, int tileRank, int tileRanks,
+                                                     uint32_t r0, uint32_t count, RtQueue rq) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= count) return;
+	const uint32_t r = r0 + i, aaSq = (uint32_t)(aa * aa);
+	const uint32_t lp = r / aaSq, k = r % aaSq;
+	int x, y;
+	if (!tilePixel(lp, W, H, tileRank, tileRanks, x, y)) { qsu(rq, RQ_PIX, i, kInactive); return; }
+	// s(x,y) / s_aa(x,y,k), q1.cpp:51-64, generalised to the n x n grid
+	const float ox = ((float)(k % (uint32_t)aa) + 0.5f) / (float)aa, oy = ((float)(k / (uint32_t)aa) + 0.5f) / (float)aa;
+	const f3 eye = ld3(cam.eye);
+	const f3 s = eye + ld3(cam.facing) + ld3(cam.right) * (2 * (((float)x + ox) / (float)W - 0.5f)) + ld3(cam.up) * (2 * (((float)y + oy) / (float)H - 0.5f));
+	const f3 d = s - eye;   // raytracer.cpp:316
+	qsf(rq, RQ_OX, i, eye.x); qsf(rq, RQ_OY, i, eye.y); qsf(rq, RQ_OZ, i, eye.z);
+	qsf(rq, RQ_DX, i, d.x); qsf(rq, RQ_DY, i, d.y); qsf(rq, RQ_DZ, i, d.z);
+	qsf(rq, RQ_WR, i, 1.0f); qsf(rq, RQ_WG, i, 1.0f); qsf(rq, RQ_WB, i, 1.0f);
+	qsu(rq, RQ_PIX, i, ((uint32_t)y * (uint32_t)W + (uint32_t)x) * aaSq + k);
+	qsu(rq, RQ_PATH, i, 1u);
+}
+
+// rays given by the caller: origin + target (trace) or origin + direction (findNearest)
+__global__ __launch_bounds__(kBlock) void k_load_rays(const float* a, const float* b, uint32_t n, int bIsTarget, RtQueue rq, uint32_t pixBase) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n) return;
+	const f3 e = ld3(a + 3 * (size_t)i), s = ld3(b + 3 * (size_t)i);
+	const f3 d = bIsTarget ? s - e : s;   // raytracer.cpp:316
+	qsf(rq, RQ_OX, i, e.x); qsf(rq, RQ_OY, i, e.y); qsf(rq, RQ_OZ, i, e.z);
+	qsf(rq, RQ_DX, i, d.x); qsf(rq, RQ_DY, i, d.y); qsf(rq, RQ_DZ, i, d.z);
+	qsf(rq, RQ_WR, i, 1.0f); qsf(rq, RQ_WG, i, 1.0f); qsf(rq, RQ_WB, i, 1.0f);
+	qsu(rq, RQ_PIX, i, pixBase + i);
+	qsu(rq, RQ_PATH, i, 1u);
+}
+
+template <bool CSG, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
+	__shared__ int32_t stack[kStack][kBlock];
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n) return;
+	if (qu(rq, RQ_PIX, i) == kInactive) { qsu(hq, HQ_PRIM, i, RT_NO_HIT); return; }
+	const f3 e = mk3(qf(rq, RQ_OX, i), qf(rq, RQ_OY, i), qf(rq, RQ_OZ, i));
+	const f3 d = mk3(qf(rq, RQ_DX, i), qf(rq, RQ_DY, i), qf(rq, RQ_DZ, i));
+	unsigned long long cn = 0, cp = 0;
+	const NearestResult r = nearestTraverse<CSG, COUNT>(S, stack, e, d, cn, cp);
+	qsu(hq, HQ_PRIM, i, r.prim);
+	qsf(hq, HQ_T, i, r.t);
+	if (CSG) qsu(hq, HQ_TAG, i, r.tag);
+	if (COUNT) { atomicAdd(&ctr->nodes, cn); atomicAdd(&ctr->prims, cp); }
+}
+
+// hit queue -> caller-visible (hit, id, t)
+__global__ __launch_bounds__(kBlock) void k_export_hits(DevScene S, RtQueue hq, uint32_t n, uint8_t* hit, int32_t* id, float* t) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t prim = qu(hq, HQ_PRIM, i);
+	const bool h = prim != RT_NO_HIT;
+	if (hit) hit[i] = h;
+	if (id) id[i] = h ? primId(S, prim) : -1;
+	if (t) t[i] = h ? qf(hq, HQ_T, i) : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Object::transmitRay objects.cpp:107-140 (+ Plane:: :224-229, Triangle:: :273-275).
+// Where the exit search on the ray's own object fails, the reference continues from whatever an earlier ray left in
+// the object's hit cache; like the oracle restatement this uses the current point / previous normal instead.
+// ---------------------------------------------------------------------------------------------------------
+template <bool CSG>
+__device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refraction, f3 inPoint, f3 inVector, f3 inNormal, f3& outPoint, f3& outVector) {
+	const uint32_t type = RT_PRIM_TYPE(ref), ix = RT_PRIM_INDEX(ref);
+	if (type == RT_PRIM_PLANE || refraction == 0) {
+		outVector = inVector;
+		outPoint = inPoint + 1e-5f * outVector;
+		return true;
+	}
+	f3 currentPoint = inPoint, innerVector = mk3(0, 0, 0), outNormal = mk3(0, 0, 0);
+	refractRay(inVector, inNormal, refraction, innerVector);
+	bool result = false;
+	int reflections = 0;
+	while (!result && reflections < RT_MAX_REFLECTIONS) {
+		f3 hp = currentPoint;
+		if (type == RT_PRIM_SPHERE) {
+			const rt_sphere s = S.spheres[ix];
+			const float t = sphereHit(ld3(s.center), s.radius, currentPoint, innerVector, true);
+			// cachedHitpoint is rewritten whenever rayhit gets past its two early returns; t == 0 can be either
+			// "missed" (no write) or "exactly at the origin" (write of e + 0*d = e): both leave hp == currentPoint.
+			if (t > 0.0f) hp = currentPoint + t * innerVector;
+			outNormal = sphereNormal(S, s, hp);
+		} else if (type == RT_PRIM_TRI) {
+			f3 nrm = outNormal;
+			const float t = meshHit(S, S.meshes[S.tris[ix].mesh], currentPoint, innerVector, true, nrm);
+			if (t > 0.0f) hp = currentPoint + t * innerVector;
+			outNormal = nrm;
+		} else if (type == RT_PRIM_BOX) {
+			const rt_box b = S.boxes[ix];
+			const float t = boxIntersect(b.b, currentPoint, innerVector, true);
+			if (!(t < 0)) hp = currentPoint + t * innerVector;
+			boxNormal(b.b, hp, outNormal);
+		} else if (CSG) {
+			const rt_csg c = S.csgs[ix];
+			uint32_t tag = 0;
+			const float t = csgEval(S, c, currentPoint, innerVector, true, tag);
+			hp = currentPoint + t * innerVector;   // csgObject::rayhit always rewrites cachedHitpoint (csg.cpp:24)
+			if (t != 0.0f) outNormal = csgNormal(S, c, currentPoint, innerVector, tag);
+		}
+		outPoint = hp;
+		result = refractRay(innerVector, outNormal, refraction, outVector);
+		if (!result) {
+			innerVector = reflectRay(-innerVector, outNormal);
+			currentPoint = outPoint;
+			reflections++;
+		}
+	}
+	return result;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// shade: everything Object::lightPoint does except the shadow rays
+// ---------------------------------------------------------------------------------------------------------
+template <bool CSG>
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtCounters* ctr,
+                                                  RtAccum A, uint32_t aaSq, int maxDepth, int wantSurfaces,
+                                                  uint8_t* outHit, int32_t* outId, float* outT) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	const bool live = i < n && qu(rq, RQ_PIX, i < n ? i : 0) != kInactive;
+	uint32_t pixKey = 0, path = 1, prim = RT_NO_HIT;
+	f3 e = mk3(0, 0, 0), d = mk3(0, 0, 1), w = mk3(0, 0, 0);
+	float t = 0;
+	if (live) {
+		pixKey = qu(rq, RQ_PIX, i); path = qu(rq, RQ_PATH, i);
+		e = mk3(qf(rq, RQ_OX, i), qf(rq, RQ_OY, i), qf(rq, RQ_OZ, i));
+		d = mk3(qf(rq, RQ_DX, i), qf(rq, RQ_DY, i), qf(rq, RQ_DZ, i));
+		w = mk3(qf(rq, RQ_WR, i), qf(rq, RQ_WG, i), qf(rq, RQ_WB, i));
+		prim = qu(hq, HQ_PRIM, i);
+		t = qf(hq, HQ_T, i);
+	}
+	const uint32_t pixel = pixKey / aaSq;
+	const bool hit = live && prim != RT_NO_HIT;
+	const f3 background = ld3(S.background);
+	if (live && path == 1u && outHit) {   // first-level results for rt_trace_batch
+		outHit[pixKey] = hit;
+		if (outId) outId[pixKey] = hit ? primId(S, prim) : -1;
+		if (outT) outT[pixKey] = hit ? t : 0.0f;
+	}
+	if (live && !hit) accumAdd(A, pixel, w * background);   // q1.cpp:143-145 / objects.cpp:68-69,94-95
+
+	bool wantR = false, wantT = false, wantS = false;
+	f3 p = mk3(0, 0, 0), N = mk3(0, 0, 0), V = mk3(0, 0, 0);
+	f3 rO = p, rD = p, rW = p, tO = p, tD = p, tW = p, wl = p;
+	float kd[3] = { 0, 0, 0 }, ks[3] = { 0, 0, 0 }, shininess = 0;
+	if (hit) {
+		const uint32_t type = RT_PRIM_TYPE(prim), ix = RT_PRIM_INDEX(prim);
+		p = e + t * d;   // cachedHitpoint of the winner (every rayhit sets e + t*d)
+		V = normalize(-d);
+		const rt_material m = S.materials[primMaterial(S, prim)];
+		float ka[3] = { m.ambient[0], m.ambient[1], m.ambient[2] };
+		kd[0] = m.diffuse[0]; kd[1] = m.diffuse[1]; kd[2] = m.diffuse[2];
+		ks[0] = m.specular[0]; ks[1] = m.specular[1]; ks[2] = m.specular[2];
+		shininess = m.shininess;
+		if (type == RT_PRIM_SPHERE) N = sphereNormal(S, S.spheres[ix], p);
+		else if (type == RT_PRIM_PLANE) N = normalize(ld3(S.planes[ix].normal));   // objects.cpp:215-217
+		else if (type == RT_PRIM_TRI) {
+			const rt_tri tr = S.tris[ix];
+			N = ld3(tr.n);
+			if (tr.uv >= 0) {   // TextureTriangle::lightPoint, texturemesh.cpp:25-52
+				const rt_uv uvs = S.uvs[tr.uv];
+				const f3 P0 = ld3(tr.p0), P1 = ld3(tr.p1), P2 = ld3(tr.p2);
+				const f3 v0 = P0 - p, v1 = P1 - p, v2 = P2 - p;
+				const float area = length(cross(P0 - P1, P0 - P2));
+				const float a0 = length(cross(v1, v2)) / area;
+				const float a1 = length(cross(v2, v0)) / area;
+				const float a2 = length(cross(v0, v1)) / area;
+				const float u = (uvs.uv[0] * a0 + uvs.uv[2] * a1) + uvs.uv[4] * a2;
+				const float v = (uvs.uv[1] * a0 + uvs.uv[3] * a1) + uvs.uv[5] * a2;
+				const int tex = S.meshes[tr.mesh].tex;
+				const int height = S.textures[tex].height, width = S.textures[tex].width;
+				const uint8_t* px = texel(S, tex, f2i(u * width), f2i(v * height));   // texturemesh.cpp:7-16
+				ka[0] = kd[0] = float(px[0]) / 255; ka[1] = kd[1] = float(px[1]) / 255; ka[2] = kd[2] = float(px[2]) / 255;
+			}
+		} else if (type == RT_PRIM_BOX) boxNormal(S.boxes[ix].b, p, N);
+		else if (CSG) N = csgNormal(S, S.csgs[ix], e, d, qu(hq, HQ_TAG, i));
+
+		const bool transmissive = !isZero3(m.transmissive);
+		const f3 kt = ld3(m.transmissive);
+		wl = transmissive ? w * (mk3(1.0f, 1.0f, 1.0f) - kt) : w;   // objects.cpp:103
+		const int depth = 31 - __clz((int)path);   // reflectionCount of this ray
+
+		// ambient lights, objects.cpp:382-387
+		f3 amb = mk3(0, 0, 0);
+		for (int l = 0; l < S.n_lights; l++)
+			if (S.lights[l].type == RT_LIGHT_AMBIENT) amb = amb + ld3(S.lights[l].colour) * ld3(ka);
+		accumAdd(A, pixel, wl * amb);
+
+		if (!isZero3(m.reflective)) {   // objects.cpp:62-75
+			const f3 R = reflectRay(V, N);
+			rO = p + 1e-5f * R;
+			rD = (p + R) - rO;
+			rW = wl * ld3(m.reflective);
+			if (depth + 1 > maxDepth) accumAdd(A, pixel, rW * background);   // raytracer.cpp:308-313 -> objects.cpp:68-69
+			else wantR = true;
+		}
+		if (transmissive) {   // objects.cpp:81-104
+			f3 outPoint, outVector;
+			if (transmitRay<CSG>(S, prim, m.refraction, p, d, N, outPoint, outVector)) {
+				tO = outPoint;
+				tD = (outPoint + outVector) - outPoint;
+				tW = w * kt;
+				if (depth + 1 > maxDepth) accumAdd(A, pixel, tW * background);
+				else wantT = true;
+			}
+		}
+		wantS = wantSurfaces != 0;
+	}
+
+	// ---- convergent part: wave-compacted appends ----
+	const uint32_t sr = wavePush(wantR, &ctr->next_count);
+	if (wantR) {
+		if (sr < nq.cap) {
+			qsf(nq, RQ_OX, sr, rO.x); qsf(nq, RQ_OY, sr, rO.y); qsf(nq, RQ_OZ, sr, rO.z);
+			qsf(nq, RQ_DX, sr, rD.x); qsf(nq, RQ_DY, sr, rD.y); qsf(nq, RQ_DZ, sr, rD.z);
+			qsf(nq, RQ_WR, sr, rW.x); qsf(nq, RQ_WG, sr, rW.y); qsf(nq, RQ_WB, sr, rW.z);
+			qsu(nq, RQ_PIX, sr, pixKey); qsu(nq, RQ_PATH, sr, path * 2u);
+		} else ctr->overflow = 1;
+	}
+	const uint32_t st = wavePush(wantT, &ctr->next_count);
+	if (wantT) {
+		if (st < nq.cap) {
+			qsf(nq, RQ_OX, st, tO.x); qsf(nq, RQ_OY, st, tO.y); qsf(nq, RQ_OZ, st, tO.z);
+			qsf(nq, RQ_DX, st, tD.x); qsf(nq, RQ_DY, st, tD.y); qsf(nq, RQ_DZ, st, tD.z);
+			qsf(nq, RQ_WR, st, tW.x); qsf(nq, RQ_WG, st, tW.y); qsf(nq, RQ_WB, st, tW.z);
+			qsu(nq, RQ_PIX, st, pixKey); qsu(nq, RQ_PATH, st, path * 2u + 1u);
+		} else ctr->overflow = 1;
+	}
+	const uint32_t ss = wavePush(wantS, &ctr->surf_count);
+	if (wantS) {
+		if (ss < sq.cap) {
+			qsf(sq, SQ_PX, ss, p.x); qsf(sq, SQ_PY, ss, p.y); qsf(sq, SQ_PZ, ss, p.z);
+			qsf(sq, SQ_NX, ss, N.x); qsf(sq, SQ_NY, ss, N.y); qsf(sq, SQ_NZ, ss, N.z);
+			qsf(sq, SQ_VX, ss, V.x); qsf(sq, SQ_VY, ss, V.y); qsf(sq, SQ_VZ, ss, V.z);
+			qsf(sq, SQ_KDR, ss, kd[0]); qsf(sq, SQ_KDG, ss, kd[1]); qsf(sq, SQ_KDB, ss, kd[2]);
+			qsf(sq, SQ_KSR, ss, ks[0]); qsf(sq, SQ_KSG, ss, ks[1]); qsf(sq, SQ_KSB, ss, ks[2]);
+			qsf(sq, SQ_SHIN, ss, shininess);
+			qsf(sq, SQ_WR, ss, wl.x); qsf(sq, SQ_WG, ss, wl.y); qsf(sq, SQ_WB, ss, wl.z);
+			qsu(sq, SQ_PIX, ss, pixKey); qsu(sq, SQ_PATH, ss, path);
+		} else ctr->overflow = 1;
+	}
+}
+
+struct Surface { f3 p, N, V, w; float kd[3], ks[3], shininess; uint32_t pixKey, path; };
+__device__ __forceinline__ Surface loadSurface(const RtQueue& sq, uint32_t s) {
+	Surface r;
+	r.p = mk3(qf(sq, SQ_PX, s), qf(sq, SQ_PY, s), qf(sq, SQ_PZ, s));
+	r.N = mk3(qf(sq, SQ_NX, s), qf(sq, SQ_NY, s), qf(sq, SQ_NZ, s));
+	r.V = mk3(qf(sq, SQ_VX, s), qf(sq, SQ_VY, s), qf(sq, SQ_VZ, s));
+	r.w = mk3(qf(sq, SQ_WR, s), qf(sq, SQ_WG, s), qf(sq, SQ_WB, s));
+	r.kd[0] = qf(sq, SQ_KDR, s); r.kd[1] = qf(sq, SQ_KDG, s); r.kd[2] = qf(sq, SQ_KDB, s);
+	r.ks[0] = qf(sq, SQ_KSR, s); r.ks[1] = qf(sq, SQ_KSG, s); r.ks[2] = qf(sq, SQ_KSB, s);
+	r.shininess = qf(sq, SQ_SHIN, s);
+	r.pixKey = qu(sq, SQ_PIX, s); r.path = qu(sq, SQ_PATH, s);
+	return r;
+}
+
+// Directional / Point / Spot lights: one shadow ray per (surface, light); consecutive lanes take consecutive
+// surfaces of the SAME light so a wave's rays share their target.
+template <bool CSG, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
+                                                         RtAccum A, uint32_t aaSq, RtCounters* ctr) {
+	__shared__ int32_t stack[kStack][kBlock];
+	const unsigned long long j = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+	if (j >= (unsigned long long)nsurf * nLights) return;
+	const uint32_t s = (uint32_t)(j % nsurf);
+	const rt_light L = S.lights[lightList[j / nsurf]];
+	const Surface sf = loadSurface(sq, s);
+	f3 Ld, lightPos;
+	if (L.type == RT_LIGHT_DIRECTIONAL) {   // objects.cpp:399-410
+		Ld = -ld3(L.direction);
+		lightPos = sf.p + RT_MAX_T * Ld;
+	} else {
+		lightPos = ld3(L.position);   // objects.cpp:422-431, 445-458
+		Ld = normalize(lightPos - sf.p);
+	}
+	f3 shadow = mk3(1.0f, 1.0f, 1.0f);
+	unsigned long long cn = 0, cp = 0;
+	const bool lit = shadowTraverse<CSG, COUNT>(S, stack, sf.p, lightPos - sf.p, shadow, cn, cp);
+	if (COUNT) { atomicAdd(&ctr->nodes, cn); atomicAdd(&ctr->prims, cp); }
+	if (!lit) return;
+	if (L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff)) return;   // objects.cpp:451
+	const f3 c = phong(ld3(L.colour) * shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
+	accumAdd(A, sf.pixKey / aaSq, sf.w * c);
+}
+
+// Rectangular / circular area light `lightIndex`: one lane per (surface, sample), samples of one surface in
+// consecutive lanes (their rays leave the same point towards neighbouring targets), summed across lanes by a
+// segmented shuffle scan so each surface costs one atomic per wave instead of one per sample.
+template <bool CSG, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t seed,
+                                                        RtAccum A, uint32_t aaSq, RtCounters* ctr) {
+	__shared__ int32_t stack[kStack][kBlock];
+	const rt_light L = S.lights[lightIndex];
+	const uint32_t ns = (uint32_t)L.samples;
+	const unsigned long long j = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+	const bool live = j < (unsigned long long)nsurf * ns;
+	uint32_t s = kInactive;
+	f3 c = mk3(0, 0, 0);
+	Surface sf;
+	sf.w = c; sf.pixKey = 0;
+	if (live) {
+		s = (uint32_t)(j / ns);
+		const uint32_t smp = (uint32_t)(j % ns);
+		sf = loadSurface(sq, s);
+		float r1, r2;
+		rng2(seed, sf.pixKey, sf.path, (uint32_t)lightIndex, smp, r1, r2);   // stands in for RAND, arealight.cpp:5
+		float xDisplacement, yDisplacement;
+		if (L.type == RT_LIGHT_RECT) {   // arealight.cpp:37-42
+			xDisplacement = (float)(((double)r1 - 0.5) * (double)L.width);
+			yDisplacement = (float)(((double)r2 - 0.5) * (double)L.height);
+		} else {   // arealight.cpp:79-87
+			const float angle = (float)((double)(r1 * 2) * RTD_PI);
+			const float displacement = L.radius * sqrtf(r2);
+			xDisplacement = displacement * cosf(angle);
+			yDisplacement = displacement * sinf(angle);
+		}
+		const f3 lightPos = ld3(L.position) + ld3(L.planeX) * xDisplacement + ld3(L.planeY) * yDisplacement;
+		f3 shadow = mk3(1.0f, 1.0f, 1.0f);
+		unsigned long long cn = 0, cp = 0;
+		const bool lit = shadowTraverse<CSG, COUNT>(S, stack, sf.p, lightPos - sf.p, shadow, cn, cp);
+		if (COUNT) { atomicAdd(&ctr->nodes, cn); atomicAdd(&ctr->prims, cp); }
+		if (lit) c = phong(ld3(L.colour) * shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
+	}
+	// segmented inclusive scan over the wave, key = surface
+	const uint32_t lane = __lane_id();
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t ks2 = __shfl_up(s, off);
+		const float ax = __shfl_up(c.x, off), ay = __shfl_up(c.y, off), az = __shfl_up(c.z, off);
+		if (lane >= (uint32_t)off && ks2 == s) { c.x += ax; c.y += ay; c.z += az; }
+	}
+	const uint32_t nextKey = __shfl_down(s, 1);
+	if (live && (lane == 63u || nextKey != s)) accumAdd(A, sf.pixKey / aaSq, sf.w * (c / (float)ns));   // arealight.cpp:21
+}
+
+// shadowRay() for caller-supplied queries (rt_shadow_batch)
+template <bool CSG>
+__global__ __launch_bounds__(kBlock) void k_shadow_query(DevScene S, const float* point, const float* lightPos, uint32_t n, uint8_t* lit, float* shadowOut) {
+	__shared__ int32_t stack[kStack][kBlock];
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n) return;
+	const f3 p = ld3(point + 3 * (size_t)i), l = ld3(lightPos + 3 * (size_t)i);
+	f3 shadow = mk3(1.0f, 1.0f, 1.0f);
+	unsigned long long cn = 0, cp = 0;
+	const bool ok = shadowTraverse<CSG, false>(S, stack, p, l - p, shadow, cn, cp);   // bvh.cpp:124
+	if (lit) lit[i] = ok;
+	if (shadowOut) { shadowOut[3 * (size_t)i] = shadow.x; shadowOut[3 * (size_t)i + 1] = shadow.y; shadowOut[3 * (size_t)i + 2] = shadow.z; }
+}
+
+// fixed point -> float RGB for the pixels of local range [lp0, lp0+count); clears the accumulators for the next frame
+__global__ __launch_bounds__(kBlock) void k_resolve(RtAccum A, int W, int H, int tileRank, int tileRanks, uint32_t lp0, uint32_t count, uint32_t aaSq,
+                                                    int linear, float* rgb) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= count) return;
+	uint32_t pixel;
+	if (linear) pixel = lp0 + i;
+	else {
+		int x, y;
+		if (!tilePixel(lp0 + i, W, H, tileRank, tileRanks, x, y)) return;
+		pixel = (uint32_t)y * (uint32_t)W + (uint32_t)x;
+	}
+	float c[3];
+	for (int k = 0; k < 3; k++) {
+		unsigned long long* a = A.rgb + (size_t)k * A.npix + pixel;
+		c[k] = (float)((double)(long long)*a * (1.0 / 4294967296.0));
+		if (aaSq > 1) c[k] = c[k] / (float)aaSq;   // q1.cpp:140
+		*a = 0ull;
+	}
+	if (A.nonfinite[pixel]) { c[0] = c[1] = c[2] = __int_as_float(0x7fc00000); A.nonfinite[pixel] = 0; }
+	if (rgb) { rgb[3 * (size_t)pixel] = c[0]; rgb[3 * (size_t)pixel + 1] = c[1]; rgb[3 * (size_t)pixel + 2] = c[2]; }
+}
+
+// multi-GPU: dense packing of a rank's tiles for the gather, and the inverse on the root
+__global__ __launch_bounds__(kBlock) void k_tiles_copy(const float* src, float* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= count) return;
+	int x, y;
+	if (!tilePixel(i, W, H, tileRank, tileRanks, x, y)) return;
+	const size_t pixel = (size_t)y * W + x;
+	for (int k = 0; k < 3; k++) {
+		if (mode == 0) dst[3 * (size_t)i + k] = src[3 * pixel + k];          // pack: frame -> dense
+		else if (mode == 1) dst[3 * pixel + k] = src[3 * (size_t)i + k];     // unpack: dense -> frame
+		else dst[3 * pixel + k] = src[3 * pixel + k];                        // merge: frame -> frame, owned pixels only
+	}
+}
+
+inline unsigned gridFor(unsigned long long n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+// =========================================================================================================
+// launch wrappers (host)
+// =========================================================================================================
+#define RT_LAUNCH(kernel, n, stream, ...) do { if ((n) > 0) hipLaunchKernelGGL(kernel, dim3(gridFor(n)), dim3(kBlock), 0, stream, __VA_ARGS__); } while (0)
+
+void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aa, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq) {
+	RT_LAUNCH(k_generate, count, st, cam, W, H, aa, tileRank, tileRanks, r0, count, rq);
+}
+void rtk_load_rays(hipStream_t st, const float* a, const float* b, uint32_t n, int bIsTarget, RtQueue rq, uint32_t pixBase) {
+	RT_LAUNCH(k_load_rays, n, st, a, b, n, bIsTarget, rq, pixBase);
+}
+void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
+	if (csg) { if (count) RT_LAUNCH((k_intersect<true, true>), n, st, S, rq, n, hq, ctr); else RT_LAUNCH((k_intersect<true, false>), n, st, S, rq, n, hq, ctr); }
+	else { if (count) RT_LAUNCH((k_intersect<false, true>), n, st, S, rq, n, hq, ctr); else RT_LAUNCH((k_intersect<false, false>), n, st, S, rq, n, hq, ctr); }
+}
+void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, uint8_t* hit, int32_t* id, float* t) {
+	RT_LAUNCH(k_export_hits, n, st, S, hq, n, hit, id, t);
+}
+void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtCounters* ctr, RtAccum A,
+               uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT) {
+	if (csg) RT_LAUNCH((k_shade<true>), n, st, S, rq, hq, n, nq, sq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT);
+	else RT_LAUNCH((k_shade<false>), n, st, S, rq, hq, n, nq, sq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT);
+}
+void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
+                      RtAccum A, uint32_t aaSq, RtCounters* ctr) {
+	const unsigned long long items = (unsigned long long)nsurf * nLights;
+	if (csg) { if (count) RT_LAUNCH((k_shadow_point<true, true>), items, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH((k_shadow_point<true, false>), items, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
+	else { if (count) RT_LAUNCH((k_shadow_point<false, true>), items, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH((k_shadow_point<false, false>), items, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
+}
+void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t samples, uint32_t seed,
+                     RtAccum A, uint32_t aaSq, RtCounters* ctr) {
+	const unsigned long long items = (unsigned long long)nsurf * samples;
+	if (csg) { if (count) RT_LAUNCH((k_shadow_area<true, true>), items, st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); else RT_LAUNCH((k_shadow_area<true, false>), items, st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); }
+	else { if (count) RT_LAUNCH((k_shadow_area<false, true>), items, st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); else RT_LAUNCH((k_shadow_area<false, false>), items, st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); }
+}
+void rtk_shadow_query(hipStream_t st, const DevScene& S, bool csg, const float* point, const float* lightPos, uint32_t n, uint8_t* lit, float* shadow) {
+	if (csg) RT_LAUNCH((k_shadow_query<true>), n, st, S, point, lightPos, n, lit, shadow);
+	else RT_LAUNCH((k_shadow_query<false>), n, st, S, point, lightPos, n, lit, shadow);
+}
+void rtk_resolve(hipStream_t st, RtAccum A, int W, int H, int tileRank, int tileRanks, uint32_t lp0, uint32_t count, uint32_t aaSq, int linear, float* rgb) {
+	RT_LAUNCH(k_resolve, count, st, A, W, H, tileRank, tileRanks, lp0, count, aaSq, linear, rgb);
+}
+void rtk_tiles_copy(hipStream_t st, const float* src, float* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode) {
+	RT_LAUNCH(k_tiles_copy, count, st, src, dst, W, H, tileRank, tileRanks, count, mode);
+}

@@ -1,0 +1,95 @@
+"""CPU suite: the oracle restatement (oracle/restate.cpp) against dumps of the REAL reference (tests/golden/ref_*.npz,
+written by tools/make_golden.py from oracle/_ref/ref_driver).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import SCENES_DET
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", list(SCENES_DET))
+def test_trace_bit_exact_vs_reference(name, flat_scenes, golden):
+    g = golden(name)
+    n = int(g["W"]) * int(g["H"])
+    r = oracle.trace_batch(flat_scenes(name), np.zeros((n, 3), np.float32), g["s"], seed=0)
+    assert np.array_equal(r["hit"], g["hit"])
+    assert np.array_equal(r["id"], g["id"])
+    assert np.array_equal(bits(r["t"]), bits(g["t"]))
+    assert np.array_equal(bits(r["rgb"]), bits(g["rgb"]))          # float RGB, bit for bit
+    assert r["rays_nearest"] == int(g["rays_nearest"]) and r["rays_shadow"] == int(g["rays_shadow"])
+
+
+@pytest.mark.parametrize("name", list(SCENES_DET))
+def test_secondary_and_shadow_rays_vs_reference(name, flat_scenes, golden):
+    g = golden(name)
+    fs = flat_scenes(name)
+    if len(g["sec_id"]):
+        r = oracle.intersect_batch(fs, g["sec_e"], g["sec_d"])
+        assert np.array_equal(r["id"], g["sec_id"])
+        assert np.array_equal(bits(r["t"]), bits(g["sec_t"]))
+    r = oracle.shadow_batch(fs, g["shd_p"], g["shd_l"])
+    assert np.array_equal(r["lit"], g["shd_lit"].astype(np.uint8))
+    assert np.array_equal(bits(r["shadow"]), bits(g["shd_shadow"]))
+
+
+def test_scene_m_same_rand_stream_is_bit_exact(flat_scenes, golden):
+    # with seed 0 the restatement draws from libc rand() in the reference's order (arealight.cpp:5)
+    g = golden("m")
+    n = int(g["W"]) * int(g["H"])
+    import ctypes
+    ctypes.CDLL(None).srand(1)
+    r = oracle.trace_batch(flat_scenes("m"), np.zeros((n, 3), np.float32), g["s"], seed=0)
+    assert np.array_equal(r["id"], g["id"])
+    assert np.array_equal(bits(r["rgb"]), bits(g["rgb"]))
+    assert r["rays_shadow"] == int(g["rays_shadow"]) == 19200 * 100
+
+
+def test_scene_m_counter_rng_matches_high_sample_reference(flat_scenes, golden):
+    # the counter-based generator that replaces rand(): 50 samples/light against the reference at 2048 samples/light
+    g, hi = golden("m"), dict(np.load(__import__("os").path.join(__import__("conftest").GOLD, "ref_m_hi.npz")))
+    n = int(g["W"]) * int(g["H"])
+    r = oracle.trace_batch(flat_scenes("m"), np.zeros((n, 3), np.float32), g["s"], seed=12345, threads=4)
+    err_counter = np.abs(np.clip(r["rgb"], 0, 1) - np.clip(hi["rgb"], 0, 1)).mean()
+    err_rand = np.abs(np.clip(g["rgb"], 0, 1) - np.clip(hi["rgb"], 0, 1)).mean()
+    # stated tolerance: mean abs error < 0.0125 (3.2/255); the reference's own 50-sample rand() image sits at 0.0103
+    assert err_counter < 0.0125
+    assert err_counter < 1.1 * err_rand            # no noisier than the reference's own 50-sample image
+    assert abs(float(r["rgb"].mean()) - float(hi["rgb"].mean())) < 1e-3   # and unbiased
+
+
+def test_supersampling_vs_reference(flat_scenes):
+    import os
+    import raytracer_amd as rt
+    from conftest import GOLD
+    g = dict(np.load(os.path.join(GOLD, "ref_c_aa2.npz")))
+    fs = flat_scenes("c")
+    cam = rt.Camera(fs.fov, 160, 120)
+    rgb, nn, ns = oracle.render(fs, cam, 160, 120, aa=2, seed=0)
+    assert np.array_equal(bits(rgb.reshape(-1, 3)), bits(g["rgb"]))
+    assert nn == int(g["rays_nearest"]) and ns == int(g["rays_shadow"])
+
+
+@pytest.mark.parametrize("name", list("acgijkl"))
+def test_640x480_rgb8_and_ids(name, flat_scenes):
+    import os
+    import raytracer_amd as rt
+    from conftest import GOLD
+    g = dict(np.load(os.path.join(GOLD, f"ref_{name}_640.npz")))
+    fs = flat_scenes(name)
+    cam = rt.Camera(fs.fov, 640, 480)
+    s = oracle.primary_targets(cam, 640, 480) if name == "a" else None   # the slow Python loop once is enough
+    rgb, nn, ns = oracle.render(fs, cam, 640, 480, seed=0, threads=4)
+    q = np.clip(np.nan_to_num(rgb.reshape(-1, 3), nan=0.0), 0, 1)
+    rgb8 = (q * np.float32(255) + np.float32(0.5)).astype(np.uint8)
+    # scene l: 2 of 307200 pixels depend on hit-cache state left by earlier rays in the reference (see restate.cpp "STATE")
+    allowed = 2 if name == "l" else 0
+    assert (rgb8 != g["rgb8"]).any(axis=1).sum() <= allowed
+    assert abs(nn - int(g["rays_nearest"])) <= allowed and abs(ns - int(g["rays_shadow"])) <= allowed
+    if s is not None:
+        r = oracle.trace_batch(fs, np.zeros((640 * 480, 3), np.float32), s, seed=0, threads=4)
+        assert np.array_equal(r["id"].astype(np.int16), g["id"])
+        assert np.array_equal(np.packbits(r["hit"]), g["hit"])

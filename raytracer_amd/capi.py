@@ -63,6 +63,13 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make lib` (hipcc, gfx950). There is no fallback path.")
+    # PyTorch ships its own libamdhip64.so.7 / libhsa-runtime64 (torch/lib).  Two HIP runtimes in one process do not
+    # share a device, so torch's copy must be the one already loaded when this library's NEEDED libamdhip64.so.7 is
+    # resolved (the dynamic linker then reuses it by SONAME).  torch is plumbing here: device buffers, streams, RCCL.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_version.restype = C.c_char_p

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the MI355X trace path on BASELINE.json's 1080p workload (config 2).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is one frame of the C2 scene (100 352-triangle textured height field + two bump-mapped spheres, ambient +
+directional + point light) at 1920x1080: generate -> intersect -> shade -> shadow -> resolve on the GPU, scene and
+queues resident in HBM, nothing crossing PCIe inside the timed region.  With N > 1 ranks the frame is sharded by
+interleaved 32x8 tiles (scene replicated per GPU), each rank packs its tiles and rank 0 gathers them over RCCL and
+unpacks them into the full frame -- that exchange is inside the timed region.  Scaling is WEAK: the sample grid
+grows with N (1x1, 2x1, 2x2, 4x2 samples per pixel for N = 1, 2, 4, 8) so every GPU traces one sample per pixel of
+its share, i.e. 1920*1080 primary rays per GPU at every N.
+
+Mrays = BVH::findNearest calls + BVH::calcShadow calls (the reference's own two ray queries, bvh.cpp:72,123).
+The JSON line also carries the roofline of the dominant kernel and the CPU restatement timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+AA_GRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# algorithmic bytes per unit of traversal work (with this build's 64 B two-child node)
+NODE_BYTES, TRI_BYTES, SPHERE_BYTES, RAY_QUEUE_BYTES, HIT_QUEUE_BYTES, SURF_BYTES = 64, 64, 32, 44, 12, 84
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--grid", type=int, default=224, help="height-field cells per side (224 -> 100 352 triangles)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save", default=None, help="write the last frame as a BMP (rank 0)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+    from raytracer_amd import scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}; launch N > 1 through torch.distributed.run", file=sys.stderr)
+        args.gpus = world
+    if rt.device_count() < 1:
+        raise RuntimeError("bench.py needs a HIP device: the trace path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    W, H = args.width, args.height
+    ax, ay = AA_GRID.get(world, (world, 1))
+    eye, rot_x = (0.0, 1.5, 1.0), -0.3
+
+    # scene: generated deterministically in the reference's JSON schema, loaded by the library's choose_scene restatement
+    with tempfile.TemporaryDirectory() as tmp:
+        path = scenes.c2_scene(tmp, grid=args.grid)
+        flat = rt.FlatScene.from_json(path)
+    scene = rt.Scene(flat, local_rank)
+    cam = rt.Camera(flat.fov, W, H, eye=eye, rot_x=rot_x)
+
+    frame = torch.zeros(H, W, 3, device=dev, dtype=torch.float32)
+    ntiles = scene.tiles_count(W, H, rank, world)
+    packed = torch.zeros(ntiles * 256 * 3, device=dev, dtype=torch.float32)
+    gather_list = None
+    if world > 1 and rank == 0:
+        gather_list = [torch.zeros(scene.tiles_count(W, H, r, world) * 256 * 3, device=dev, dtype=torch.float32) for r in range(world)]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step(flags=0):
+        st = scene.render_into(frame.data_ptr(), W, H, aa=(ax, ay), camera=cam, tile_rank=rank, tile_ranks=world, stream=stream, flags=flags)
+        if world > 1:
+            # tiles -> rank 0 (RCCL gather over xGMI), then de-interleave into the full frame
+            scene.tiles_pack(frame.data_ptr(), packed.data_ptr(), W, H, rank, world, stream=stream)
+            sizes_equal = all(scene.tiles_count(W, H, r, world) == ntiles for r in range(world))
+            if sizes_equal:
+                dist.gather(packed, gather_list, dst=0)
+            else:   # ragged tile counts: point-to-point into rank 0
+                if rank == 0:
+                    reqs = [dist.irecv(gather_list[r], src=r) for r in range(1, world)]
+                    gather_list[0].copy_(packed)
+                    for q in reqs:
+                        q.wait()
+                else:
+                    dist.send(packed, dst=0)
+            if rank == 0:
+                for r in range(1, world):
+                    scene.tiles_unpack(gather_list[r].data_ptr(), frame.data_ptr(), W, H, r, world, stream=stream)
+        return st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    rays = 0
+    for _ in range(args.steps):
+        st = step()
+        rays += st["rays_nearest"] + st["rays_shadow"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        rr = torch.tensor([rays], device=dev, dtype=torch.int64)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        rays = int(rr.item())
+
+    # ---- roofline of the dominant kernel: live hipEvent timing of the traversal launches + an untimed counting pass ----
+    timed = [step(flags=rt.RT_FLAG_TIME_KERNELS) for _ in range(3)][-1]
+    counted = step(flags=rt.RT_FLAG_COUNTERS)
+    barrier()
+    roofline = None
+    if rank == 0:
+        near_ms, shad_ms = timed["nearest_ms"], timed["shadow_ms"]
+        nlaunch_near = max(1, timed["levels"])
+        n_sph = flat.info.n_spheres
+        # algorithmic bytes: nodes read, primitive records tested, queue records read and written
+        near_bytes = (counted["nodes_nearest"] * NODE_BYTES + counted["prims_nearest"] * TRI_BYTES +
+                      counted["rays_nearest"] * (RAY_QUEUE_BYTES + HIT_QUEUE_BYTES))
+        shad_bytes = (counted["nodes_shadow"] * NODE_BYTES + counted["prims_shadow"] * TRI_BYTES + counted["rays_shadow"] * SURF_BYTES)
+        if shad_ms >= near_ms:
+            kname, ms, nbytes, launches = "k_shadow_point", shad_ms, shad_bytes, max(1, timed["levels"])
+        else:
+            kname, ms, nbytes, launches = "k_intersect", near_ms, near_bytes, nlaunch_near
+        achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launch_ms": round(ms / launches, 4), "launches_per_step": launches,
+                    "algorithmic_bytes_per_launch": int(nbytes / launches),
+                    "nearest_ms": round(near_ms, 4), "shadow_ms": round(shad_ms, 4),
+                    "nodes_per_ray_nearest": round(counted["nodes_nearest"] / max(1, counted["rays_nearest"]), 2),
+                    "nodes_per_ray_shadow": round(counted["nodes_shadow"] / max(1, counted["rays_shadow"]), 2),
+                    "prims_per_ray_nearest": round(counted["prims_nearest"] / max(1, counted["rays_nearest"]), 2),
+                    "prims_per_ray_shadow": round(counted["prims_shadow"] / max(1, counted["rays_shadow"]), 2),
+                    "spheres": int(n_sph)}
+
+    # ---- CPU baseline: the oracle restatement (bit-identical to the compiled reference on the bundled scenes) ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle
+        cw, ch = W // 4, H // 4
+        ccam = rt.Camera(flat.fov, cw, ch, eye=eye, rot_x=rot_x)
+        threads = min(16, os.cpu_count() or 1)
+        t1 = time.perf_counter()
+        _, n1, s1 = oracle.render(flat, ccam, cw, ch, seed=1, threads=1)
+        d1 = time.perf_counter() - t1
+        reps, tot, t2 = 0, 0, time.perf_counter()
+        while time.perf_counter() - t2 < 10.0:
+            _, nn, ns = oracle.render(flat, ccam, cw, ch, seed=1, threads=threads)
+            tot += nn + ns
+            reps += 1
+        dN = time.perf_counter() - t2
+        cpu = {"value": round(tot / dN / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+               "sample": f"same C2 scene and camera at {cw}x{ch} (1/16 of the pixels), full ray tree, {reps} frames in {dN:.1f} s on {threads} threads",
+               "single_thread_value": round((n1 + s1) / d1 / 1e6, 3)}
+
+    if rank == 0:
+        if args.save:
+            rt.write_bmp(args.save, frame.cpu().numpy())
+        value = rays / elapsed / 1e6
+        out = {
+            "metric": "Mrays/sec (primary+secondary) at 1080p", "value": round(value, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C2: {flat.info.n_tris}-triangle textured height field + 2 bump spheres, ambient+directional+point light, "
+                                   f"{W}x{H}, {ax}x{ay} samples/pixel, tiles sharded over {world} GPU(s)",
+                       "width": W, "height": H, "samples_per_pixel": ax * ay, "rays_per_step": rays // args.steps,
+                       "eye": list(eye), "rot_x": rot_x, "max_depth": rt.MAX_REFLECTIONS},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,8 +39,10 @@ typedef struct rt_scene rt_scene;   /* device-resident scene + work queues */
 typedef struct rt_stats {
 	uint64_t rays_nearest;     /* BVH::findNearest calls   (bvh.cpp:72)  : primary + reflection + transmission */
 	uint64_t rays_shadow;      /* BVH::calcShadow calls    (bvh.cpp:123) */
-	uint64_t nodes_visited;    /* 64 B BVH nodes read, nearest + shadow (only when RT_FLAG_COUNTERS) */
-	uint64_t prim_tests;       /* primitive rayhit evaluations          (only when RT_FLAG_COUNTERS) */
+	uint64_t nodes_nearest;    /* 64 B BVH nodes read by the nearest-hit kernel   (only when RT_FLAG_COUNTERS) */
+	uint64_t prims_nearest;    /* primitive rayhit evaluations in it              (only when RT_FLAG_COUNTERS) */
+	uint64_t nodes_shadow;     /* ... and the same two for the shadow kernels */
+	uint64_t prims_shadow;
 	uint64_t levels;           /* wavefront iterations executed (ray-tree depth reached + 1) */
 	uint64_t batch_splits;     /* times a pixel batch was re-run in halves because a ray queue overflowed */
 	float    gpu_ms;           /* hipEvent time of the whole call on `stream`, upload/download excluded */
@@ -49,7 +51,7 @@ typedef struct rt_stats {
 	float    pad;
 } rt_stats;
 
-#define RT_FLAG_COUNTERS   1u   /* count nodes_visited / prim_tests in the traversal kernels (slower) */
+#define RT_FLAG_COUNTERS   1u   /* count nodes / primitive tests in the traversal kernels (slower) */
 #define RT_FLAG_TIME_KERNELS 2u /* bracket each traversal launch with hipEvents to fill nearest_ms / shadow_ms */
 
 /* ------------------------------------------------------------------------------------------------------
@@ -92,18 +94,18 @@ void rt_scene_free(rt_scene* scene);
 
 /* Renders a frame: the display() pixel loop (q1.cpp:130-147) over trace() (raytracer.cpp:307-329), i.e.
  * generate -> [intersect -> shade -> shadow]* -> resolve on the GPU.
- *   aa            sub-pixel grid per axis: 1 = s(x,y) (q1.cpp:51-53), 2 = the reference's 4x s_aa (q1.cpp:55-64),
- *                 n = n*n samples at ((i+.5)/n, (j+.5)/n)
+ *   aa_x, aa_y    sub-pixel sample grid: 1x1 = s(x,y) (q1.cpp:51-53), 2x2 = the reference's four s_aa samples
+ *                 (q1.cpp:55-64); in general aa_x*aa_y samples at ((i+.5)/aa_x, (j+.5)/aa_y), averaged (q1.cpp:140)
  *   max_depth     MAX_REFLECTIONS (raytracer.h:7); the reference value is 16
  *   tile_rank, tile_ranks   render only the 32x8-pixel tiles t with t % tile_ranks == tile_rank (multi-GPU
  *                 sharding); the other pixels of rgb_dev are left untouched.  (0,1) = whole frame.
  *   seed          seeds the counter-based generator that replaces rand() in arealight.cpp:5
  *   rgb_dev       DEVICE buffer, width*height*3 floats, row 0 = bottom row; miss = background colour
  * Enqueues on `stream`, waits for completion, fills *stats if not NULL. */
-int rt_render(rt_scene* scene, const rt_camera* camera, int width, int height, int aa, int max_depth,
+int rt_render(rt_scene* scene, const rt_camera* camera, int width, int height, int aa_x, int aa_y, int max_depth,
               int tile_rank, int tile_ranks, uint32_t seed, uint32_t flags, float* rgb_dev, void* stream, rt_stats* stats);
 /* Convenience: same, into a HOST buffer (allocates a temporary device frame). */
-int rt_render_host(rt_scene* scene, const rt_camera* camera, int width, int height, int aa, int max_depth,
+int rt_render_host(rt_scene* scene, const rt_camera* camera, int width, int height, int aa_x, int aa_y, int max_depth,
                    uint32_t seed, uint32_t flags, float* rgb_host, rt_stats* stats);
 
 /* trace() for n rays at once (raytracer.h:16, raytracer.cpp:307-329): ray i runs from e[i] towards s[i]

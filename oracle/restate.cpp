@@ -607,8 +607,8 @@ struct Tracer {
 	}
 };
 
-V3 primaryTarget(const rt_camera* c, int W, int H, int x, int y, int aa, int k) {   // q1.cpp:51-64
-	float ox = ((k % aa) + 0.5f) / aa, oy = ((k / aa) + 0.5f) / aa;
+V3 primaryTarget(const rt_camera* c, int W, int H, int x, int y, int aaX, int aaY, int k) {   // q1.cpp:51-64
+	float ox = ((k % aaX) + 0.5f) / aaX, oy = ((k / aaX) + 0.5f) / aaY;
 	return V3(c->eye) + V3(c->facing) + V3(c->right) * (2 * ((x + ox) / W - 0.5f)) + V3(c->up) * (2 * ((y + oy) / H - 0.5f));
 }
 
@@ -627,8 +627,8 @@ template <class F> void parallelFor(size_t n, int threads, F f) {
 
 extern "C" {
 
-void oracle_primary_target(const rt_camera* camera, int width, int height, int x, int y, int aa, int k, float out[3]) {
-	V3 s = primaryTarget(camera, width, height, x, y, aa, k);
+void oracle_primary_target(const rt_camera* camera, int width, int height, int x, int y, int aa_x, int aa_y, int k, float out[3]) {
+	V3 s = primaryTarget(camera, width, height, x, y, aa_x, aa_y, k);
 	out[0] = s.x; out[1] = s.y; out[2] = s.z;
 }
 
@@ -680,9 +680,10 @@ int oracle_shadow_batch(const rt_flat_scene* scene, const float* point, const fl
 	return 0;
 }
 
-int oracle_render(const rt_flat_scene* scene, const rt_camera* camera, int width, int height, int aa, int max_depth, uint32_t seed,
+int oracle_render(const rt_flat_scene* scene, const rt_camera* camera, int width, int height, int aa_x, int aa_y, int max_depth, uint32_t seed,
                   float* rgb, uint64_t counts[2], int threads) {
-	if (!scene || !camera || !rgb || width <= 0 || height <= 0 || aa <= 0) return -1;
+	if (!scene || !camera || !rgb || width <= 0 || height <= 0 || aa_x <= 0 || aa_y <= 0) return -1;
+	const int aaSq = aa_x * aa_y;
 	if (seed == 0) threads = 1;
 	std::vector<uint64_t> cn(std::max(threads, 1), 0), cs(std::max(threads, 1), 0);
 	// rows are dealt round-robin so that expensive image regions spread over the threads
@@ -692,13 +693,13 @@ int oracle_render(const rt_flat_scene* scene, const rt_camera* camera, int width
 			for (int x = 0; x < width; x++) {
 				size_t i = (size_t)y * width + x;
 				V3 total(0.0, 0.0, 0.0);
-				for (int k = 0; k < aa * aa; k++) {   // q1.cpp:131-146
-					T.rayIndex = (uint32_t)(i * (size_t)(aa * aa) + k);
+				for (int k = 0; k < aaSq; k++) {   // q1.cpp:131-146
+					T.rayIndex = (uint32_t)(i * (size_t)aaSq + k);
 					V3 colour;
-					if (!T.trace(V3(camera->eye), primaryTarget(camera, width, height, x, y, aa, k), colour, 0, 1, nullptr)) colour = V3(scene->background);
+					if (!T.trace(V3(camera->eye), primaryTarget(camera, width, height, x, y, aa_x, aa_y, k), colour, 0, 1, nullptr)) colour = V3(scene->background);
 					total = total + colour;
 				}
-				if (aa > 1) total = total / float(aa * aa);
+				if (aaSq > 1) total = total / float(aaSq);
 				rgb[3 * i] = total.x; rgb[3 * i + 1] = total.y; rgb[3 * i + 2] = total.z;
 			}
 		cn[tid] = T.nNear; cs[tid] = T.nShadow;

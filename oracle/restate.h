@@ -34,12 +34,13 @@ int oracle_intersect_batch(const rt_flat_scene* scene, const float* e, const flo
 int oracle_shadow_batch(const rt_flat_scene* scene, const float* point, const float* light_pos, size_t n,
                         uint8_t* lit, float* shadow);
 
-/* display()'s pixel loop (q1.cpp:130-147) with the n x n sub-pixel grid; rgb row 0 = bottom row. */
-int oracle_render(const rt_flat_scene* scene, const rt_camera* camera, int width, int height, int aa, int max_depth, uint32_t seed,
+/* display()'s pixel loop (q1.cpp:130-147) with an aa_x x aa_y sub-pixel grid (1x1 and 2x2 are the reference's);
+ * rgb row 0 = bottom row. */
+int oracle_render(const rt_flat_scene* scene, const rt_camera* camera, int width, int height, int aa_x, int aa_y, int max_depth, uint32_t seed,
                   float* rgb, uint64_t counts[2], int threads);
 
 /* primary ray targets s(x,y) / s_aa (q1.cpp:51-64) for sample k of the n x n grid, into out[3] */
-void oracle_primary_target(const rt_camera* camera, int width, int height, int x, int y, int aa, int k, float out[3]);
+void oracle_primary_target(const rt_camera* camera, int width, int height, int x, int y, int aa_x, int aa_y, int k, float out[3]);
 
 #ifdef __cplusplus
 }

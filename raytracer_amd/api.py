@@ -8,6 +8,11 @@ from . import capi
 from .capi import rt_camera, rt_flat_scene, rt_stats, check, ptr, f32
 
 
+def _aa(aa):
+    """aa: n (the reference's n x n grid: 1 or 2) or an (aa_x, aa_y) pair."""
+    return (int(aa), int(aa)) if np.isscalar(aa) else (int(aa[0]), int(aa[1]))
+
+
 def device_count():
     return int(capi.load().rt_device_count())
 
@@ -93,9 +98,10 @@ class Scene:
     def render(self, width, height, aa=1, max_depth=capi.MAX_REFLECTIONS, seed=1, flags=0, camera=None):
         """One frame into host memory: float32 [H, W, 3], row 0 = bottom row (q1.cpp's GL convention)."""
         cam = camera or self.camera(width, height)
+        ax, ay = _aa(aa)
         out = np.empty((height, width, 3), np.float32)
         st = rt_stats()
-        check(capi.load().rt_render_host(self._h, C.byref(cam.c), width, height, aa, max_depth, seed, flags, ptr(out), C.byref(st)))
+        check(capi.load().rt_render_host(self._h, C.byref(cam.c), width, height, ax, ay, max_depth, seed, flags, ptr(out), C.byref(st)))
         self.last_stats = st.as_dict()
         return out
 
@@ -103,8 +109,9 @@ class Scene:
                     tile_rank=0, tile_ranks=1, stream=None):
         """One frame (or this rank's tiles of it) into a DEVICE buffer of width*height*3 floats; returns the stats."""
         cam = camera or self.camera(width, height)
+        ax, ay = _aa(aa)
         st = rt_stats()
-        check(capi.load().rt_render(self._h, C.byref(cam.c), width, height, aa, max_depth, tile_rank, tile_ranks, seed, flags,
+        check(capi.load().rt_render(self._h, C.byref(cam.c), width, height, ax, ay, max_depth, tile_rank, tile_ranks, seed, flags,
                                     C.c_void_p(frame_dev_ptr), C.c_void_p(stream or 0), C.byref(st)))
         self.last_stats = st.as_dict()
         return self.last_stats

@@ -35,7 +35,8 @@ class rt_camera(C.Structure):
 
 
 class rt_stats(C.Structure):
-    _fields_ = [("rays_nearest", C.c_uint64), ("rays_shadow", C.c_uint64), ("nodes_visited", C.c_uint64), ("prim_tests", C.c_uint64),
+    _fields_ = [("rays_nearest", C.c_uint64), ("rays_shadow", C.c_uint64), ("nodes_nearest", C.c_uint64), ("prims_nearest", C.c_uint64),
+                ("nodes_shadow", C.c_uint64), ("prims_shadow", C.c_uint64),
                 ("levels", C.c_uint64), ("batch_splits", C.c_uint64), ("gpu_ms", C.c_float), ("nearest_ms", C.c_float),
                 ("shadow_ms", C.c_float), ("pad", C.c_float)]
 
@@ -84,9 +85,9 @@ def load():
     lib.rt_scene_upload.argtypes = [C.POINTER(rt_flat_scene), C.c_int, C.POINTER(C.c_void_p)]
     lib.rt_scene_free.argtypes = [C.c_void_p]
     lib.rt_scene_free.restype = None
-    lib.rt_render.argtypes = [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+    lib.rt_render.argtypes = [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                               C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]
-    lib.rt_render_host.argtypes = [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+    lib.rt_render_host.argtypes = [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                                    C.c_void_p, C.POINTER(rt_stats)]
     lib.rt_trace_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]

@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
 	rt_camera_setup(flat->fov, W, H, eye, rotX, rotY, &cam);
 	std::vector<float> rgb((size_t)W * H * 3);
 	rt_stats st;
-	if ((rc = rt_render_host(sc, &cam, W, H, aa, depth, 1, 0, rgb.data(), &st)) != RT_OK) { fprintf(stderr, "%s\n", rt_last_error()); return 1; }
+	if ((rc = rt_render_host(sc, &cam, W, H, aa, aa, depth, 1, 0, rgb.data(), &st)) != RT_OK) { fprintf(stderr, "%s\n", rt_last_error()); return 1; }
 	if ((rc = rt_write_bmp(out.c_str(), rgb.data(), W, H)) != RT_OK) { fprintf(stderr, "%s\n", rt_last_error()); return 1; }
 	const double rays = (double)st.rays_nearest + (double)st.rays_shadow;
 	printf("{\"scene\": \"%s\", \"width\": %d, \"height\": %d, \"aa\": %d, \"rays_nearest\": %llu, \"rays_shadow\": %llu, \"gpu_ms\": %.3f, \"mrays_per_s\": %.1f, \"out\": \"%s\"}\n",

@@ -63,7 +63,7 @@ struct rt_scene {
 	}
 	int ensureAccum(uint32_t npix) {
 		if (accum.npix >= npix && accum.rgb) return RT_OK;
-		if (accum.rgb) { hipFree(accum.rgb); hipFree(accum.nonfinite); accum.rgb = nullptr; accum.nonfinite = nullptr; accum.npix = 0; }
+		if (accum.rgb) { (void)hipFree(accum.rgb); (void)hipFree(accum.nonfinite); accum.rgb = nullptr; accum.nonfinite = nullptr; accum.npix = 0; }
 		HIPCHK(hipMalloc((void**)&accum.rgb, (size_t)npix * 3 * sizeof(unsigned long long)));
 		HIPCHK(hipMalloc((void**)&accum.nonfinite, (size_t)npix));
 		HIPCHK(hipMemset(accum.rgb, 0, (size_t)npix * 3 * sizeof(unsigned long long)));
@@ -94,7 +94,7 @@ int treeDepth(const rt_flat_scene* s) {
 struct Source {
 	bool camera = false;
 	rt_camera cam{};
-	int W = 0, H = 0, aa = 1, tileRank = 0, tileRanks = 1;
+	int W = 0, H = 0, aaX = 1, aaY = 1, tileRank = 0, tileRanks = 1;
 	const float* a = nullptr; const float* b = nullptr;   // device arrays for ray batches (origin, target)
 	uint8_t* outHit = nullptr; int32_t* outId = nullptr; float* outT = nullptr;
 };
@@ -114,7 +114,7 @@ struct Run {
 	int levels(uint32_t r0, uint32_t cnt) {
 		const bool count = (flags & RT_FLAG_COUNTERS) != 0, timeK = (flags & RT_FLAG_TIME_KERNELS) != 0;
 		int cur = 0;
-		if (src.camera) rtk_generate(st, src.cam, src.W, src.H, src.aa, src.tileRank, src.tileRanks, r0, cnt, sc->ray[0]);
+		if (src.camera) rtk_generate(st, src.cam, src.W, src.H, src.aaX, src.aaY, src.tileRank, src.tileRanks, r0, cnt, sc->ray[0]);
 		else rtk_load_rays(st, src.a + 3 * (size_t)r0, src.b + 3 * (size_t)r0, cnt, 1, sc->ray[0], r0);
 		uint32_t n = cnt;
 		bool shadowPending = false;
@@ -194,7 +194,10 @@ int finish(rt_scene* sc, hipStream_t st, Run& run, rt_stats* stats) {
 	if (run.flags & RT_FLAG_COUNTERS) HIPCHK(hipMemcpyAsync(sc->ctrHost, sc->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
 	HIPCHK(hipEventElapsedTime(&run.stats.gpu_ms, sc->ev[0], sc->ev[1]));
-	if (run.flags & RT_FLAG_COUNTERS) { run.stats.nodes_visited = sc->ctrHost->nodes; run.stats.prim_tests = sc->ctrHost->prims; }
+	if (run.flags & RT_FLAG_COUNTERS) {
+		run.stats.nodes_nearest = sc->ctrHost->nodes_nearest; run.stats.prims_nearest = sc->ctrHost->prims_nearest;
+		run.stats.nodes_shadow = sc->ctrHost->nodes_shadow; run.stats.prims_shadow = sc->ctrHost->prims_shadow;
+	}
 	if (stats) *stats = run.stats;
 	return RT_OK;
 }
@@ -216,7 +219,7 @@ int64_t ownedPixels(int W, int H, int rank, int ranks) {
 
 struct DevBuf {   // scoped device allocation
 	void* p = nullptr;
-	~DevBuf() { if (p) hipFree(p); }
+	~DevBuf() { if (p) (void)hipFree(p); }
 	int alloc(size_t bytes) { HIPCHK(hipMalloc(&p, std::max<size_t>(bytes, 16))); return RT_OK; }
 	template <class T> T* as() { return static_cast<T*>(p); }
 };
@@ -300,27 +303,27 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 
 void rt_scene_free(rt_scene* sc) {
 	if (!sc) return;
-	hipSetDevice(sc->device);
-	for (void* p : sc->allocs) hipFree(p);
-	if (sc->accum.rgb) hipFree(sc->accum.rgb);
-	if (sc->accum.nonfinite) hipFree(sc->accum.nonfinite);
-	if (sc->ctrHost) hipHostFree(sc->ctrHost);
-	for (auto& ev : sc->ev) if (ev) hipEventDestroy(ev);
+	(void)hipSetDevice(sc->device);
+	for (void* p : sc->allocs) (void)hipFree(p);
+	if (sc->accum.rgb) (void)hipFree(sc->accum.rgb);
+	if (sc->accum.nonfinite) (void)hipFree(sc->accum.nonfinite);
+	if (sc->ctrHost) (void)hipHostFree(sc->ctrHost);
+	for (auto& ev : sc->ev) if (ev) (void)hipEventDestroy(ev);
 	delete sc;
 }
 
-int rt_render(rt_scene* sc, const rt_camera* camera, int width, int height, int aa, int max_depth, int tile_rank, int tile_ranks,
+int rt_render(rt_scene* sc, const rt_camera* camera, int width, int height, int aa_x, int aa_y, int max_depth, int tile_rank, int tile_ranks,
               uint32_t seed, uint32_t flags, float* rgb_dev, void* stream, rt_stats* stats) {
-	if (!sc || !camera || !rgb_dev || width <= 0 || height <= 0 || aa < 1 || aa > 16 || max_depth < 0 || max_depth > 30 ||
-	    tile_ranks < 1 || tile_rank < 0 || tile_rank >= tile_ranks || (int64_t)width * height > (1ll << 31) / (aa * aa)) {
+	if (!sc || !camera || !rgb_dev || width <= 0 || height <= 0 || aa_x < 1 || aa_x > 16 || aa_y < 1 || aa_y > 16 || max_depth < 0 || max_depth > 30 ||
+	    tile_ranks < 1 || tile_rank < 0 || tile_rank >= tile_ranks || (int64_t)width * height > (1ll << 31) / (aa_x * aa_y)) {
 		rt::set_error("rt_render: bad argument");
 		return RT_EINVAL;
 	}
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	if (int rc = begin(sc, st, flags)) return rc;
 	if (int rc = sc->ensureAccum((uint32_t)(width * height))) return rc;
-	Run run{ sc, st, {}, max_depth, seed, flags, (uint32_t)(aa * aa) };
-	run.src.camera = true; run.src.cam = *camera; run.src.W = width; run.src.H = height; run.src.aa = aa;
+	Run run{ sc, st, {}, max_depth, seed, flags, (uint32_t)(aa_x * aa_y) };
+	run.src.camera = true; run.src.cam = *camera; run.src.W = width; run.src.H = height; run.src.aaX = aa_x; run.src.aaY = aa_y;
 	run.src.tileRank = tile_rank; run.src.tileRanks = tile_ranks;
 	const uint64_t localPix = (uint64_t)localTiles(width, height, tile_rank, tile_ranks) * 256;
 	if (int rc = run.all(localPix * run.aaSq)) return rc;
@@ -330,14 +333,14 @@ int rt_render(rt_scene* sc, const rt_camera* camera, int width, int height, int 
 	return finish(sc, st, run, stats);
 }
 
-int rt_render_host(rt_scene* sc, const rt_camera* camera, int width, int height, int aa, int max_depth, uint32_t seed, uint32_t flags,
+int rt_render_host(rt_scene* sc, const rt_camera* camera, int width, int height, int aa_x, int aa_y, int max_depth, uint32_t seed, uint32_t flags,
                    float* rgb_host, rt_stats* stats) {
 	if (!sc || !rgb_host || width <= 0 || height <= 0) { rt::set_error("rt_render_host: bad argument"); return RT_EINVAL; }
 	HIPCHK(hipSetDevice(sc->device));
 	DevBuf frame;
 	const size_t bytes = (size_t)width * height * 3 * sizeof(float);
 	if (int rc = frame.alloc(bytes)) return rc;
-	if (int rc = rt_render(sc, camera, width, height, aa, max_depth, 0, 1, seed, flags, frame.as<float>(), nullptr, stats)) return rc;
+	if (int rc = rt_render(sc, camera, width, height, aa_x, aa_y, max_depth, 0, 1, seed, flags, frame.as<float>(), nullptr, stats)) return rc;
 	HIPCHK(hipMemcpy(rgb_host, frame.p, bytes, hipMemcpyDeviceToHost));
 	return RT_OK;
 }

@@ -22,8 +22,8 @@ struct RtCounters {
 	uint32_t surf_count;      // surface records appended
 	uint32_t overflow;        // an append found its queue full (the batch is re-run in halves)
 	uint32_t pad;
-	unsigned long long nodes; // RT_FLAG_COUNTERS
-	unsigned long long prims;
+	unsigned long long nodes_nearest, prims_nearest;   // RT_FLAG_COUNTERS: 64 B nodes read / primitive tests in k_intersect
+	unsigned long long nodes_shadow, prims_shadow;     // ... and in the shadow kernels
 };
 
 // 32.32 fixed-point accumulators: three planes of npix, plus a per-pixel "saw a NaN/inf" byte
@@ -31,7 +31,7 @@ struct RtAccum { unsigned long long* rgb; uint8_t* nonfinite; uint32_t npix; };
 
 using rtd::DevScene;
 
-void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aa, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq);
+void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, int aaY, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq);
 void rtk_load_rays(hipStream_t st, const float* a, const float* b, uint32_t n, int bIsTarget, RtQueue rq, uint32_t pixBase);
 void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr);
 void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, uint8_t* hit, int32_t* id, float* t);

@@ -264,16 +264,16 @@ __device__ __forceinline__ bool shadowTraverse(const DevScene& S, int32_t (*stac
 // kernels
 // =========================================================================================================
 
-__global__ __launch_bounds__(kBlock) void k_generate(rt_camera cam, int W, int H, int aa, int tileRank, int tileRanks,
+__global__ __launch_bounds__(kBlock) void k_generate(rt_camera cam, int W, int H, int aaX, int aaY, int tileRank, int tileRanks,
                                                      uint32_t r0, uint32_t count, RtQueue rq) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= count) return;
-	const uint32_t r = r0 + i, aaSq = (uint32_t)(aa * aa);
+	const uint32_t r = r0 + i, aaSq = (uint32_t)(aaX * aaY);
 	const uint32_t lp = r / aaSq, k = r % aaSq;
 	int x, y;
 	if (!tilePixel(lp, W, H, tileRank, tileRanks, x, y)) { qsu(rq, RQ_PIX, i, kInactive); return; }
-	// s(x,y) / s_aa(x,y,k), q1.cpp:51-64, generalised to the n x n grid
-	const float ox = ((float)(k % (uint32_t)aa) + 0.5f) / (float)aa, oy = ((float)(k / (uint32_t)aa) + 0.5f) / (float)aa;
+	// s(x,y) / s_aa(x,y,k), q1.cpp:51-64, generalised to an aaX x aaY sub-pixel grid (1x1 and 2x2 are the reference's)
+	const float ox = ((float)(k % (uint32_t)aaX) + 0.5f) / (float)aaX, oy = ((float)(k / (uint32_t)aaX) + 0.5f) / (float)aaY;
 	const f3 eye = ld3(cam.eye);
 	const f3 s = eye + ld3(cam.facing) + ld3(cam.right) * (2 * (((float)x + ox) / (float)W - 0.5f)) + ld3(cam.up) * (2 * (((float)y + oy) / (float)H - 0.5f));
 	const f3 d = s - eye;   // raytracer.cpp:316
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RtQueue rq, ui
 	qsu(hq, HQ_PRIM, i, r.prim);
 	qsf(hq, HQ_T, i, r.t);
 	if (CSG) qsu(hq, HQ_TAG, i, r.tag);
-	if (COUNT) { atomicAdd(&ctr->nodes, cn); atomicAdd(&ctr->prims, cp); }
+	if (COUNT) { atomicAdd(&ctr->nodes_nearest, cn); atomicAdd(&ctr->prims_nearest, cp); }
 }
 
 // hit queue -> caller-visible (hit, id, t)
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq,
 	f3 shadow = mk3(1.0f, 1.0f, 1.0f);
 	unsigned long long cn = 0, cp = 0;
 	const bool lit = shadowTraverse<CSG, COUNT>(S, stack, sf.p, lightPos - sf.p, shadow, cn, cp);
-	if (COUNT) { atomicAdd(&ctr->nodes, cn); atomicAdd(&ctr->prims, cp); }
+	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
 	if (!lit) return;
 	if (L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff)) return;   // objects.cpp:451
 	const f3 c = phong(ld3(L.colour) * shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, 
 		f3 shadow = mk3(1.0f, 1.0f, 1.0f);
 		unsigned long long cn = 0, cp = 0;
 		const bool lit = shadowTraverse<CSG, COUNT>(S, stack, sf.p, lightPos - sf.p, shadow, cn, cp);
-		if (COUNT) { atomicAdd(&ctr->nodes, cn); atomicAdd(&ctr->prims, cp); }
+		if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
 		if (lit) c = phong(ld3(L.colour) * shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
 	}
 	// segmented inclusive scan over the wave, key = surface
@@ -663,8 +663,8 @@ inline unsigned gridFor(unsigned long long n) { return (unsigned)((n + kBlock - 
 // =========================================================================================================
 #define RT_LAUNCH(kernel, n, stream, ...) do { if ((n) > 0) hipLaunchKernelGGL(kernel, dim3(gridFor(n)), dim3(kBlock), 0, stream, __VA_ARGS__); } while (0)
 
-void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aa, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq) {
-	RT_LAUNCH(k_generate, count, st, cam, W, H, aa, tileRank, tileRanks, r0, count, rq);
+void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, int aaY, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq) {
+	RT_LAUNCH(k_generate, count, st, cam, W, H, aaX, aaY, tileRank, tileRanks, r0, count, rq);
 }
 void rtk_load_rays(hipStream_t st, const float* a, const float* b, uint32_t n, int bIsTarget, RtQueue rq, uint32_t pixBase) {
 	RT_LAUNCH(k_load_rays, n, st, a, b, n, bIsTarget, rq, pixBase);

@@ -1,0 +1,220 @@
+"""Deterministic synthetic scenes for the BASELINE.json configs, written in the reference's own
+JSON scene schema (raytracer.cpp:134-300) plus procedurally generated 24-bit BMP textures, so they go through the
+same loader as the bundled scenes.  Nothing here is read from the reference at run time.
+
+    C2  ~100k-triangle textured height field + two bump-mapped spheres   (the 1080p headline workload)
+    C3  8x8 lattice of nested CSG objects, reflective / refractive, depth 5
+    C4  area-light soft shadows, 64 samples per light
+    C5  ~5M-triangle height field (generated at reduced size unless asked; see c5_scene)
+"""
+import json
+import math
+import os
+import struct
+
+import numpy as np
+
+
+def write_bmp24(path, rgb):
+    """rgb: uint8 [H, W, 3], row 0 = top.  Uncompressed 24-bit BMP (what EasyBMP reads, EasyBMP.cpp:668)."""
+    h, w = rgb.shape[:2]
+    row = (w * 3 + 3) // 4 * 4
+    data = np.zeros((h, row), np.uint8)
+    data[:, : w * 3] = rgb[::-1, :, ::-1].reshape(h, w * 3)   # bottom-up rows, BGR
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", 54 + row * h, 0, 0, 54))
+        f.write(struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, row * h, 3780, 3780, 0, 0))
+        f.write(data.tobytes())
+
+
+def _hash01(ix, iz, seed):
+    """Integer lattice hash -> [0,1), vectorised (the 'hash-noise' of the height fields)."""
+    h = (ix.astype(np.uint64) * np.uint64(0x9E3779B1) + iz.astype(np.uint64) * np.uint64(0x85EBCA77) + np.uint64(seed) * np.uint64(0xC2B2AE3D)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x2C1B3C6D)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(12)
+    h = (h * np.uint64(0x297A2D39)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    return (h & np.uint64(0xFFFFFF)).astype(np.float64) / float(1 << 24)
+
+
+def tiles_texture(size=1024, cells=16):
+    y, x = np.mgrid[0:size, 0:size]
+    c = ((x * cells // size) + (y * cells // size)) % 2
+    grout = ((x % (size // cells)) < 3) | ((y % (size // cells)) < 3)
+    img = np.zeros((size, size, 3), np.uint8)
+    img[..., 0] = np.where(c, 200, 60) + (x * 40 // size)
+    img[..., 1] = np.where(c, 180, 70) + (y * 50 // size)
+    img[..., 2] = np.where(c, 150, 110)
+    img[grout] = (30, 30, 35)
+    return img
+
+
+def bump_texture(size=512, seed=7):
+    y, x = np.mgrid[0:size, 0:size].astype(np.float64)
+    v = np.zeros((size, size))
+    for octave, amp in ((8, 0.5), (16, 0.3), (32, 0.2)):
+        gx, gy = x * octave / size, y * octave / size
+        ix, iy = np.floor(gx).astype(np.int64), np.floor(gy).astype(np.int64)
+        fx, fy = gx - ix, gy - iy
+        fx, fy = fx * fx * (3 - 2 * fx), fy * fy * (3 - 2 * fy)
+        a = _hash01(ix % octave, iy % octave, seed + octave)
+        b = _hash01((ix + 1) % octave, iy % octave, seed + octave)
+        c = _hash01(ix % octave, (iy + 1) % octave, seed + octave)
+        d = _hash01((ix + 1) % octave, (iy + 1) % octave, seed + octave)
+        v += amp * ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy)
+    g = np.clip(v * 255, 0, 255).astype(np.uint8)
+    return np.stack([g, g, g], axis=-1)
+
+
+def _fmt(v):
+    return float(np.float32(v))
+
+
+def height_field(n, seed, x0=-8.0, x1=8.0, z0=-17.0, z1=-1.0):
+    """n x n cells -> (triangles [2n^2, 3, 3], uv [2n^2, 3, 2]); normals face +y (triangles are back-face culled)."""
+    ix, iz = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="ij")
+    x = x0 + (x1 - x0) * ix / n
+    z = z0 + (z1 - z0) * iz / n
+    y = -1.2 + 0.3 * np.sin(1.7 * x) * np.cos(1.3 * z) + _hash01(ix, iz, seed) * 0.02
+    P = np.stack([x, y, z], axis=-1).astype(np.float32)            # [n+1, n+1, 3]
+    UV = np.stack([ix / n, iz / n], axis=-1).astype(np.float32)
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[:-1, 1:], P[1:, 1:]
+    ua, ub, uc, ud = UV[:-1, :-1], UV[1:, :-1], UV[:-1, 1:], UV[1:, 1:]
+    tris = np.stack([np.stack([a, c, b], axis=2), np.stack([b, c, d], axis=2)], axis=2).reshape(-1, 3, 3)
+    uvs = np.stack([np.stack([ua, uc, ub], axis=2), np.stack([ub, uc, ud], axis=2)], axis=2).reshape(-1, 3, 2)
+    return tris, uvs
+
+
+def _mesh_json(tris, uvs=None):
+    out = {"triangles": tris.astype(np.float64).round(7).tolist()}
+    if uvs is not None:
+        out["uvCoords"] = uvs.astype(np.float64).round(7).tolist()
+    return out
+
+
+def c2_scene(out_dir, grid=224):
+    """BASELINE config 2: textured triangle mesh (grid*grid*2 triangles, 224 -> 100 352) with bump mapping."""
+    os.makedirs(out_dir, exist_ok=True)
+    write_bmp24(os.path.join(out_dir, "gen_tiles.bmp"), tiles_texture())
+    write_bmp24(os.path.join(out_dir, "gen_bump1.bmp"), bump_texture(seed=7))
+    write_bmp24(os.path.join(out_dir, "gen_bump2.bmp"), bump_texture(seed=21))
+    tris, uvs = height_field(grid, seed=1)
+    mesh = {"type": "texturemesh", "texture": "gen_tiles.bmp",
+            "material": {"specular": [0.2, 0.2, 0.2], "shininess": 12.0}}
+    mesh.update(_mesh_json(tris, uvs))
+    scene = {
+        "camera": {"field": 60, "background": [0.25, 0.35, 0.55]},
+        "objects": [
+            mesh,
+            {"type": "bumpsphere", "radius": 1.0, "position": [-1.6, -0.1, -6.5], "bumpmap": "gen_bump1.bmp", "bumpdepth": 2.0,
+             "material": {"ambient": [0.2, 0.1, 0.1], "diffuse": [0.8, 0.3, 0.2], "specular": [0.5, 0.5, 0.5], "shininess": 20.0}},
+            {"type": "bumpsphere", "radius": 1.2, "position": [1.7, 0.2, -8.0], "bumpmap": "gen_bump2.bmp", "bumpdepth": 3.0,
+             "material": {"ambient": [0.1, 0.1, 0.2], "diffuse": [0.2, 0.4, 0.8], "specular": [0.6, 0.6, 0.6], "shininess": 40.0}},
+        ],
+        "lights": [
+            {"type": "ambient", "color": [0.25, 0.25, 0.25]},
+            {"type": "directional", "color": [0.7, 0.7, 0.65], "direction": [-0.4, -1.0, -0.3]},
+            {"type": "point", "color": [0.5, 0.45, 0.4], "position": [2.0, 4.0, -3.0]},
+        ],
+    }
+    path = os.path.join(out_dir, f"c2_{grid}.json")
+    with open(path, "w") as f:
+        json.dump(scene, f)
+    return path
+
+
+def _csg_cell(cx, cz, s):
+    """The k.json pattern: difference(intersection(box, sphere), union(box, union(box, box))) -- 5 leaves, depth 4."""
+    def box(ax, ay, az, bx, by, bz):
+        return {"type": "box", "point1": [_fmt(cx + ax * s), _fmt(-1 + ay * s), _fmt(cz + az * s)], "point2": [_fmt(cx + bx * s), _fmt(-1 + by * s), _fmt(cz + bz * s)]}
+    return {
+        "operation": "difference",
+        "first": {"operation": "intersection", "first": box(-1, 0, -1, 1, 2, 1),
+                  "second": {"type": "sphere", "position": [_fmt(cx), _fmt(-1 + s), _fmt(cz)], "radius": _fmt(1.35 * s)}},
+        "second": {"operation": "union", "first": box(-0.5, 0.5, -1.5, 0.5, 1.5, 1.5),
+                   "second": {"operation": "union", "first": box(-1.5, 0.5, -0.5, 1.5, 1.5, 0.5), "second": box(-0.5, -0.5, -0.5, 0.5, 2.5, 0.5)}},
+    }
+
+
+def c3_scene(out_dir):
+    """BASELINE config 3: 64 nested CSG objects on an 8x8 lattice; half reflective 0.5, a quarter transmissive 0.6 / ior 1.33."""
+    os.makedirs(out_dir, exist_ok=True)
+    objects = [{"type": "plane", "position": [0, -1, 0], "normal": [0, 1, 0],
+                "material": {"ambient": [0.1, 0.1, 0.1], "diffuse": [0.5, 0.5, 0.45], "reflective": [0.2, 0.2, 0.2]}}]
+    for i in range(8):
+        for j in range(8):
+            cx, cz = -5.25 + 1.5 * i, -4.0 - 1.5 * j
+            k = i * 8 + j
+            mat = {"ambient": [0.1 + 0.05 * (k % 3), 0.1, 0.15], "diffuse": [0.3 + 0.08 * (i % 5), 0.3 + 0.08 * (j % 5), 0.4],
+                   "specular": [0.5, 0.5, 0.5], "shininess": 30.0}
+            if k % 2 == 0:
+                mat["reflective"] = [0.5, 0.5, 0.5]
+            if k % 4 == 1:
+                mat["transmissive"] = [0.6, 0.6, 0.6]
+                mat["refraction"] = 1.33
+            obj = {"type": "csgobject", "material": mat}
+            obj.update(_csg_cell(cx, cz, 0.45))
+            objects.append(obj)
+    scene = {"camera": {"field": 60, "background": [0.1, 0.12, 0.2]}, "objects": objects,
+             "lights": [{"type": "ambient", "color": [0.3, 0.3, 0.3]},
+                        {"type": "directional", "color": [0.8, 0.8, 0.75], "direction": [-0.3, -1.0, -0.5]}]}
+    path = os.path.join(out_dir, "c3.json")
+    with open(path, "w") as f:
+        json.dump(scene, f)
+    return path
+
+
+def c4_scene(out_dir, samples=64):
+    """BASELINE config 4: a room with CSG furniture lit by a rectangular and a circular area light, `samples` each."""
+    os.makedirs(out_dir, exist_ok=True)
+    objects = [
+        {"type": "plane", "position": [0, -1, 0], "normal": [0, 1, 0], "material": {"diffuse": [0.55, 0.5, 0.45]}},
+        {"type": "plane", "position": [0, 2.5, 0], "normal": [0, -1, 0], "material": {"diffuse": [0.6, 0.6, 0.6]}},
+        {"type": "plane", "position": [-3, 0, 0], "normal": [1, 0, 0.2], "material": {"diffuse": [0.7, 0.4, 0.4]}},
+        {"type": "plane", "position": [3, 0, 0], "normal": [-1, 0, 0.2], "material": {"diffuse": [0.4, 0.4, 0.7]}},
+        {"type": "plane", "position": [0, 0, -8], "normal": [0, 0, 1], "material": {"diffuse": [0.6, 0.6, 0.55]}},
+        {"type": "csgobject", "material": {"diffuse": [0.5, 0.3, 0.15], "specular": [0.2, 0.2, 0.2], "shininess": 10.0},
+         "operation": "difference",
+         "first": {"type": "box", "point1": [-1.0, -1.0, -3.5], "point2": [1.0, -0.2, -5.0]},
+         "second": {"operation": "union",
+                    "first": {"type": "box", "point1": [-0.8, -1.1, -3.3], "point2": [0.8, -0.35, -5.2]},
+                    "second": {"type": "box", "point1": [-1.1, -1.1, -3.7], "point2": [1.1, -0.35, -4.8]}}},
+        {"type": "sphere", "radius": 0.35, "position": [0.3, 0.15, -4.2],
+         "material": {"diffuse": [0.9, 0.1, 0.1], "specular": [1, 1, 1], "shininess": 30.0}},
+        {"type": "sphere", "radius": 0.5, "position": [-1.6, -0.5, -5.5],
+         "material": {"diffuse": [0.2, 0.7, 0.3], "specular": [0.5, 0.5, 0.5], "shininess": 15.0}},
+        {"type": "box", "point1": [1.2, -1.0, -5.5], "point2": [2.0, 0.4, -6.3], "material": {"diffuse": [0.7, 0.7, 0.2]}},
+        {"type": "csgobject", "material": {"diffuse": [0.8, 0.5, 0.7]}, "operation": "difference",
+         "first": {"type": "sphere", "position": [0, 1.6, -4.5], "radius": 0.5},
+         "second": {"type": "box", "point1": [-0.6, 1.0, -3.9], "point2": [0.6, 1.6, -5.1]}},
+    ]
+    lights = [
+        {"type": "ambient", "color": [0.15, 0.15, 0.15]},
+        {"type": "rectangular", "color": [0.6, 0.6, 0.55], "position": [-1.0, 2.4, -4.0], "normal": [0, -1, 0], "orientation": [1, 0, 0],
+         "width": 1.2, "height": 0.8, "samples": samples},
+        {"type": "circular", "color": [0.5, 0.5, 0.55], "position": [1.5, 2.3, -5.5], "normal": [-0.2, -1, 0.1], "radius": 0.5, "samples": samples},
+    ]
+    scene = {"camera": {"field": 60, "background": [0, 0, 0]}, "objects": objects, "lights": lights}
+    path = os.path.join(out_dir, f"c4_{samples}.json")
+    with open(path, "w") as f:
+        json.dump(scene, f)
+    return path
+
+
+def c5_scene(out_dir, grid=1581):
+    """BASELINE config 5: height field of grid*grid*2 triangles (1581 -> 4 999 122) + floor + two lights.
+    The JSON is ~0.6 GB at full size; pass a smaller grid for tests."""
+    os.makedirs(out_dir, exist_ok=True)
+    tris, _ = height_field(grid, seed=2)
+    mesh = {"type": "mesh", "material": {"ambient": [0.1, 0.12, 0.1], "diffuse": [0.45, 0.6, 0.4], "specular": [0.2, 0.2, 0.2], "shininess": 8.0}}
+    mesh.update(_mesh_json(tris))
+    scene = {"camera": {"field": 60, "background": [0.3, 0.4, 0.6]},
+             "objects": [mesh, {"type": "plane", "position": [0, -1.6, 0], "normal": [0, 1, 0], "material": {"diffuse": [0.3, 0.3, 0.35]}}],
+             "lights": [{"type": "ambient", "color": [0.25, 0.25, 0.25]},
+                        {"type": "directional", "color": [0.7, 0.7, 0.65], "direction": [-0.4, -1.0, -0.3]},
+                        {"type": "point", "color": [0.5, 0.45, 0.4], "position": [2.0, 4.0, -3.0]}]}
+    path = os.path.join(out_dir, f"c5_{grid}.json")
+    with open(path, "w") as f:
+        json.dump(scene, f)
+    return path

@@ -55,7 +55,8 @@ def shadow_batch(flat, p, l):
 def render(flat, cam, width, height, aa=1, max_depth=16, seed=0, threads=1):
     rgb = np.zeros((height, width, 3), np.float32)
     cnt = (C.c_uint64 * 2)(0, 0)
-    rc = lib().oracle_render(flat._h, C.byref(cam.c), int(width), int(height), int(aa), int(max_depth), C.c_uint32(seed), _p(rgb), cnt, int(threads))
+    ax, ay = (int(aa), int(aa)) if np.isscalar(aa) else (int(aa[0]), int(aa[1]))
+    rc = lib().oracle_render(flat._h, C.byref(cam.c), int(width), int(height), ax, ay, int(max_depth), C.c_uint32(seed), _p(rgb), cnt, int(threads))
     assert rc == 0
     return rgb, int(cnt[0]), int(cnt[1])
 
@@ -69,7 +70,7 @@ def primary_targets(cam, width, height, aa=1):
     for y in range(height):
         for x in range(width):
             for k in range(aa * aa):
-                f(C.byref(cam.c), int(width), int(height), x, y, int(aa), k, buf)
+                f(C.byref(cam.c), int(width), int(height), x, y, int(aa), int(aa), k, buf)
                 out[i] = buf[:]
                 i += 1
     return out

@@ -27,9 +27,10 @@ extern "C" {
 #endif
 
 enum { RT_PRIM_SPHERE = 0, RT_PRIM_TRI = 1, RT_PRIM_BOX = 2, RT_PRIM_CSG = 3, RT_PRIM_PLANE = 4, RT_PRIM_NONE = 15 };
-#define RT_PRIM_TYPE(ref)  ((uint32_t)(ref) >> 28)
+#define RT_PRIM_TYPE(ref)  (((uint32_t)(ref) >> 28) & 7u)
 #define RT_PRIM_INDEX(ref) ((uint32_t)(ref) & 0x0fffffffu)
 #define RT_PRIM_REF(type, index) (((uint32_t)(type) << 28) | (uint32_t)(index))
+#define RT_PRIM_LAST 0x80000000u   /* set on the last entry of every leaf's run in leaf_prims[] */
 #define RT_NO_HIT 0xffffffffu
 
 enum { RT_LIGHT_AMBIENT = 0, RT_LIGHT_DIRECTIONAL = 1, RT_LIGHT_POINT = 2, RT_LIGHT_SPOT = 3, RT_LIGHT_RECT = 4, RT_LIGHT_CIRC = 5 };
@@ -99,7 +100,7 @@ typedef struct rt_flat_scene {
 	const rt_texture* textures;
 	const uint8_t* texels;
 	const rt_bvh_node* bvh_nodes;
-	const uint32_t* leaf_prims;  /* RT_PRIM_REF(type, index into the typed array) */
+	const uint32_t* leaf_prims;  /* RT_PRIM_REF(type, index into the typed array) | RT_PRIM_LAST on a leaf's last entry */
 } rt_flat_scene;
 
 /* Camera basis as q1.cpp:30-44 leaves it: right/up already scaled by w and h. */

@@ -305,7 +305,7 @@ struct Tracer {
 		} else {
 			int32_t first = ~child;
 			for (int i = 0; i < count; i++) {
-				uint32_t ref = S->leaf_prims[first + i];
+				uint32_t ref = S->leaf_prims[first + i] & ~RT_PRIM_LAST;
 				V3 hp, nrm;
 				t = primHit(ref, e, d, hp, nrm);
 				if (t > 1e-5 && t < t_min) { hit.prim = ref; hit.t = t; hit.point = hp; hit.normal = nrm; t_min = t; }
@@ -339,7 +339,7 @@ struct Tracer {
 		} else {
 			int32_t first = ~child;
 			for (int i = 0; i < count; i++) {
-				uint32_t ref = S->leaf_prims[first + i];
+				uint32_t ref = S->leaf_prims[first + i] & ~RT_PRIM_LAST;
 				V3 hp, nrm;
 				float t = primHit(ref, e, d, hp, nrm);
 				if (t < 1.0 && t * length(d) > 1e-5) {

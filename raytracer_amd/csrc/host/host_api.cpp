@@ -19,7 +19,11 @@ namespace rt {
 static bool childOk(const rt_flat_scene* s, int32_t child, int32_t count) {
 	if (child >= 0) return child < s->n_bvh_nodes && count == 0;
 	int64_t first = ~(int64_t)child;
-	return count >= 0 && first + count <= s->n_leaf_prims;
+	if (count < 1 || first + count > s->n_leaf_prims) return false;
+	// the device walks a leaf until it meets RT_PRIM_LAST: exactly the last entry of the run must carry it
+	for (int64_t k = 0; k < count; k++)
+		if (((s->leaf_prims[first + k] & RT_PRIM_LAST) != 0) != (k == count - 1)) return false;
+	return true;
 }
 
 int validate_flat_scene(const rt_flat_scene* s) {
@@ -76,7 +80,7 @@ int validate_flat_scene(const rt_flat_scene* s) {
 		RT_CHECK(L.type >= RT_LIGHT_AMBIENT && L.type <= RT_LIGHT_CIRC, "light type");
 		RT_CHECK(L.type < RT_LIGHT_RECT || (L.samples >= 0 && L.samples <= (1 << 20)), "area light sample count");
 	}
-	RT_CHECK(childOk(s, s->root_child, s->root_count), "root reference");
+	RT_CHECK((s->root_child < 0 && s->root_count == 0) || childOk(s, s->root_child, s->root_count), "root reference");
 	for (int i = 0; i < s->n_bvh_nodes; i++)
 		for (int k = 0; k < 2; k++) {
 			RT_CHECK(childOk(s, s->bvh_nodes[i].child[k], s->bvh_nodes[i].count[k]), "bvh child reference");

@@ -196,6 +196,7 @@ struct Loader {
 			childOut = ~(int32_t)S->leaf_prims.size();
 			countOut = (int32_t)objs.size();
 			for (int oi : objs) emitLeafPrim(bvhObjs[oi]);
+			S->leaf_prims.back() |= RT_PRIM_LAST;   // device leaf loops run until this flag instead of carrying a count
 			return;
 		}
 		float lengthX = box.b[1] - box.b[0], lengthY = box.b[3] - box.b[2], lengthZ = box.b[5] - box.b[4];
@@ -429,7 +430,7 @@ void rt_flat_scene_free(rt_flat_scene* scene) {
 }  // extern "C"
 
 // ---- binary form -------------------------------------------------------------------------------------
-static const char kMagic[8] = { 'R', 'T', 'S', 'C', '0', '0', '0', '2' };
+static const char kMagic[8] = { 'R', 'T', 'S', 'C', '0', '0', '0', '3' };
 
 template <class T> static bool wr(FILE* f, const T* p, int64_t count) {
 	uint64_t n = count > 0 ? (uint64_t)count : 0;

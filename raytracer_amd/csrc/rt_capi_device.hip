@@ -37,6 +37,7 @@ struct rt_scene {
 	uint64_t shadowRaysPerSurface = 0;
 	// queues
 	uint32_t qcap = 0;
+	int maxBlocks = 2048;            // grid of the persistent kernels: 8 workgroups per CU
 	RtQueue ray[2]{}, hitq{}, surfq{};
 	RtCounters* ctr = nullptr;       // device
 	RtCounters* ctrHost = nullptr;   // pinned
@@ -120,9 +121,9 @@ struct Run {
 		bool shadowPending = false;
 		uint64_t nearRays = 0, shadowRays = 0, nLevels = 0;
 		for (int level = 0; level <= maxDepth && n > 0; level++) {
-			HIPCHK(hipMemsetAsync(sc->ctr, 0, 2 * sizeof(uint32_t), st));   // next_count, surf_count
+			HIPCHK(hipMemsetAsync(sc->ctr, 0, 4 * sizeof(uint32_t), st));   // next_count, surf_count, head_nearest, head_shadow
 			if (timeK) HIPCHK(hipEventRecord(sc->ev[2], st));
-			rtk_intersect(st, sc->dev, sc->hasCsg, count, sc->ray[cur], n, sc->hitq, sc->ctr);
+			rtk_intersect(st, sc->dev, sc->hasCsg, count, sc->maxBlocks, sc->ray[cur], n, sc->hitq, sc->ctr);
 			if (timeK) HIPCHK(hipEventRecord(sc->ev[3], st));
 			rtk_shade(st, sc->dev, sc->hasCsg, sc->ray[cur], sc->hitq, n, sc->ray[cur ^ 1], sc->surfq, sc->ctr, sc->accum, aaSq, maxDepth,
 			          sc->shadowRaysPerSurface > 0, level == 0 ? src.outHit : nullptr, src.outId, src.outT);
@@ -139,7 +140,7 @@ struct Run {
 			const uint32_t nsurf = sc->ctrHost->surf_count;
 			if (nsurf > 0 && sc->shadowRaysPerSurface > 0) {
 				if (timeK) HIPCHK(hipEventRecord(sc->ev[4], st));
-				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, sc->surfq, nsurf, sc->pointLights, sc->nPointLights, sc->accum, aaSq, sc->ctr);
+				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, sc->maxBlocks, sc->surfq, nsurf, sc->pointLights, sc->nPointLights, sc->accum, aaSq, sc->ctr);
 				for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, count, sc->surfq, nsurf, al.first, al.second, seed, sc->accum, aaSq, sc->ctr);
 				if (timeK) { HIPCHK(hipEventRecord(sc->ev[5], st)); shadowPending = true; }
 				shadowRays += (uint64_t)nsurf * sc->shadowRaysPerSurface;
@@ -244,8 +245,11 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { rt::set_error("no HIP device available: the MI355X path has no CPU fallback"); return RT_EHIP; }
 	if (device < 0 || device >= ndev) { rt::set_error("rt_scene_upload: no such device"); return RT_EINVAL; }
 	HIPCHK(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, device));
 	rt_scene* sc = new rt_scene();
 	sc->device = device;
+	sc->maxBlocks = std::max(1, prop.multiProcessorCount) * (int)envU32("RT_BLOCKS_PER_CU", 8);
 	auto fail = [&](int rc) { rt_scene_free(sc); return rc; };
 	DevScene& D = sc->dev;
 	int rc;
@@ -394,8 +398,9 @@ int rt_intersect_batch(rt_scene* sc, const float* e, const float* d, size_t n, u
 	Run run{ sc, st, {}, 0, 0, flags, 1u };
 	for (size_t c0 = 0; c0 < n; c0 += sc->qcap) {
 		const uint32_t cnt = (uint32_t)std::min<size_t>(sc->qcap, n - c0);
+		HIPCHK(hipMemsetAsync(sc->ctr, 0, 4 * sizeof(uint32_t), st));
 		rtk_load_rays(st, de.as<float>() + 3 * c0, dd.as<float>() + 3 * c0, cnt, 0, sc->ray[0], 0);
-		rtk_intersect(st, sc->dev, sc->hasCsg, (flags & RT_FLAG_COUNTERS) != 0, sc->ray[0], cnt, sc->hitq, sc->ctr);
+		rtk_intersect(st, sc->dev, sc->hasCsg, (flags & RT_FLAG_COUNTERS) != 0, sc->maxBlocks, sc->ray[0], cnt, sc->hitq, sc->ctr);
 		rtk_export_hits(st, sc->dev, sc->hitq, cnt, dhit.as<uint8_t>() + c0, did.as<int32_t>() + c0, dt.as<float>() + c0);
 		run.stats.rays_nearest += cnt;
 	}

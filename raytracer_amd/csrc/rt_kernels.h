@@ -20,6 +20,8 @@ enum { SQ_PX, SQ_PY, SQ_PZ, SQ_NX, SQ_NY, SQ_NZ, SQ_VX, SQ_VY, SQ_VZ, SQ_KDR, SQ
 struct RtCounters {
 	uint32_t next_count;      // rays appended to the next level's queue
 	uint32_t surf_count;      // surface records appended
+	uint32_t head_nearest;    // work cursors of the persistent kernels
+	uint32_t head_shadow;     // ---- the four words above are reset at the start of every level ----
 	uint32_t overflow;        // an append found its queue full (the batch is re-run in halves)
 	uint32_t pad;
 	unsigned long long nodes_nearest, prims_nearest;   // RT_FLAG_COUNTERS: 64 B nodes read / primitive tests in k_intersect
@@ -33,11 +35,11 @@ using rtd::DevScene;
 
 void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, int aaY, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq);
 void rtk_load_rays(hipStream_t st, const float* a, const float* b, uint32_t n, int bIsTarget, RtQueue rq, uint32_t pixBase);
-void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr);
+void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr);
 void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, uint8_t* hit, int32_t* id, float* t);
 void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtCounters* ctr, RtAccum A,
                uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT);
-void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
+void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                       RtAccum A, uint32_t aaSq, RtCounters* ctr);
 void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t samples, uint32_t seed,
                      RtAccum A, uint32_t aaSq, RtCounters* ctr);

@@ -19,6 +19,7 @@
 //   k_resolve       fixed point -> float RGB (+ the /4 of q1.cpp:140 for supersampling)
 #include "rt_kernels.h"
 #include "rt_device.h"
+#include <algorithm>
 
 using namespace rtd;
 
@@ -116,149 +117,165 @@ __device__ __forceinline__ int primId(const DevScene& S, uint32_t ref) {
 	return -1;
 }
 
-struct NodeRegs { float b0[6], b1[6]; int32_t c0, c1, n0, n1; };
+struct NodeRegs { float b0[6], b1[6]; int32_t c0, c1; };
 __device__ __forceinline__ NodeRegs loadNode(const rt_bvh_node* n) {   // one 64 B record = 4 x 16 B loads
 	const float4* q = reinterpret_cast<const float4*>(n);
-	const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+	const float4 a = q[0], b = q[1], c = q[2];
+	const float2 d = *reinterpret_cast<const float2*>(q + 3);
 	NodeRegs r;
 	r.b0[0] = a.x; r.b0[1] = a.y; r.b0[2] = a.z; r.b0[3] = a.w; r.b0[4] = b.x; r.b0[5] = b.y;
 	r.b1[0] = b.z; r.b1[1] = b.w; r.b1[2] = c.x; r.b1[3] = c.y; r.b1[4] = c.z; r.b1[5] = c.w;
-	r.c0 = __float_as_int(d.x); r.c1 = __float_as_int(d.y); r.n0 = __float_as_int(d.z); r.n1 = __float_as_int(d.w);
+	r.c0 = __float_as_int(d.x); r.c1 = __float_as_int(d.y);
 	return r;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// BVH::findNearest (bvh.cpp:72-92) + findRecursive (bvh.cpp:94-121)
+// Node test.  BoundingBox::intersect (objects.cpp:11-44) divides six times per box; on the device a correctly
+// rounded fp32 divide is ~11 VALU instructions, which made the two-box node test ~2/3 of all instructions.
+// Here the slabs are first evaluated with one multiply by the ray's precomputed 1/d (same compare/select
+// sequence, so zero / infinite / NaN cases behave exactly as with the divide).  Those t values are within 2 ulp of
+// the reference's, so every decision taken with a relative margin of 1e-6 is the reference's decision; only when
+// tnear/tfar/t_limit are closer than the margin is the exact divide-based test evaluated (rare, divergent).
+// Returns 0 = skip, 1 = visit, 2 = undecided.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void slabMul(float mn, float mx, float e, float inv, float& tnear, float& tfar) {
+	float t1 = (mn - e) * inv;
+	float t2 = (mx - e) * inv;
+	if (t1 > t2) { float s = t1; t1 = t2; t2 = s; }
+	if (t1 > tnear) tnear = t1;
+	if (t2 < tfar) tfar = t2;
+}
+__device__ __forceinline__ int boxClassify(const float* b, const f3& e, const f3& inv, float tlimit, float& tEntry) {
+	float tnear = -RT_MAX_T, tfar = RT_MAX_T;
+	slabMul(b[0], b[1], e.x, inv.x, tnear, tfar);
+	slabMul(b[2], b[3], e.y, inv.y, tnear, tfar);
+	slabMul(b[4], b[5], e.z, inv.z, tnear, tfar);
+	tEntry = tnear;
+	if (tnear > 3.0e38f || tfar < -3.0e38f) return 0;   // a zero direction component with the origin outside the slab: exact
+	const float m = 1e-6f * (fabsf(tnear) + fabsf(tfar)) + 1e-30f;
+	const float m2 = 1e-6f * (fabsf(tnear) + fabsf(tlimit));
+	if (tnear > tfar + m || tfar < -m || tnear > tlimit + m2) return 0;   // certainly missed, or certainly beyond the limit
+	if (tnear < tfar - m && tfar > m && tnear < tlimit - m2) return 1;    // certainly hit within the limit
+	return 2;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Per-lane traversal state for both queries:
+//   nearest  BVH::findNearest (bvh.cpp:72-92) + findRecursive (bvh.cpp:94-121)
+//   any-hit  BVH::calcShadow (bvh.cpp:123-126) + shadowRecursive (bvh.cpp:128-160)
 //
-// The reference walks left-then-right and keeps the FIRST of equal-t hits (strict <).  This walk visits the nearer
-// child first, which prunes far more, and reproduces the reference's winner by breaking t ties with the
+// The reference walks left-then-right and keeps the FIRST of equal-t hits (strict <).  The nearest walk visits the
+// nearer child first, which prunes far more, and reproduces the reference's winner by breaking t ties with the
 // primitive's position in the reference's DFS leaf order (key = index into leaf_prims + 1; planes, which the
-// reference tests before the tree, have key 0).
+// reference tests before the tree, have key 0).  For the any-hit query the order is free (an opaque occluder ends
+// it whatever came before; the attenuation product commutes).  Planes are not in the tree and never occlude.
+//
+// The walk is organised "while-while": every lane first descends through inner nodes until it holds a leaf (or is
+// done), then all lanes test their leaf's primitives together, so box code and primitive code do not alternate
+// inside a divergent wave.  `cur` >= 0: inner node, < 0: leaf at leaf_prims[~cur], kEmpty: finished.
 // ---------------------------------------------------------------------------------------------------------
-struct NearestResult { uint32_t prim; float t; uint32_t tag; };
+constexpr int32_t kEmpty = 0x7fffffff;
 
-template <bool CSG, bool COUNT>
-__device__ __forceinline__ NearestResult nearestTraverse(const DevScene& S, int32_t (*stack)[kBlock], f3 e, f3 d, unsigned long long& cntNodes, unsigned long long& cntPrims) {
-	const int tid = threadIdx.x;
-	float tmin = RT_MAX_T;   // bvh.cpp:73
-	NearestResult best;
-	best.prim = RT_NO_HIT; best.t = 0; best.tag = 0;
-	uint32_t bestKey = 0;
+struct Trav {
+	f3 e, d, inv;
+	int32_t cur;
+	int sp;
+	float tmin; uint32_t best, bestKey, bestTag;   // nearest
+	f3 shadow; float len; bool lit;                 // any-hit
+	unsigned long long cntNodes, cntPrims;
+};
 
-	for (int i = 0; i < S.n_planes; i++) {   // bvh.cpp:77-86
-		const float4 a = *reinterpret_cast<const float4*>(S.planes + i);
-		const float2 b = *reinterpret_cast<const float2*>(S.planes[i].normal + 1);
-		const float t = planeHit(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), e, d, false);
-		if (t > 0 && t < tmin) { best.prim = RT_PRIM_REF(RT_PRIM_PLANE, i); tmin = t; }
-	}
-
-	auto testLeaf = [&](int32_t first, int32_t count) {   // bvh.cpp:109-118
-		for (int k = 0; k < count; k++) {
-			const uint32_t ref = S.leaf_prims[first + k];
-			uint32_t tag = 0;
-			const float t = primHit<CSG>(S, ref, e, d, tag);
-			if (COUNT) cntPrims++;
-			const uint32_t key = (uint32_t)(first + k) + 1u;
-			if ((double)t > 1e-5 && (t < tmin || (t == tmin && key < bestKey))) { best.prim = ref; best.tag = tag; tmin = t; bestKey = key; }
+template <bool ANYHIT>
+__device__ __forceinline__ void travInit(const DevScene& S, Trav& T, f3 e, f3 d) {
+	T.e = e; T.d = d;
+	T.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	T.sp = 0; T.cur = kEmpty;
+	T.cntNodes = 0; T.cntPrims = 0;
+	T.tmin = RT_MAX_T; T.best = RT_NO_HIT; T.bestKey = 0; T.bestTag = 0;   // bvh.cpp:73
+	T.shadow = mk3(1.0f, 1.0f, 1.0f); T.lit = true; T.len = 0;
+	if (!ANYHIT) {
+		for (int i = 0; i < S.n_planes; i++) {   // bvh.cpp:77-86
+			const float4 a = *reinterpret_cast<const float4*>(S.planes + i);
+			const float2 b = *reinterpret_cast<const float2*>(S.planes[i].normal + 1);
+			const float t = planeHit(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), e, d, false);
+			if (t > 0 && t < T.tmin) { T.best = RT_PRIM_REF(RT_PRIM_PLANE, i); T.tmin = t; }
 		}
-	};
-
-	if (!(S.root_child < 0 && S.root_count == 0)) {
-		const float tr = boxIntersect(S.root_box, e, d, false);   // bvh.cpp:97-100 at the root
-		if (!(tr < 0 || tr > tmin)) {
-			if (S.root_child < 0) testLeaf(~S.root_child, S.root_count);
-			else {
-				int sp = 0;
-				int32_t node = S.root_child;
-				while (true) {
-					const NodeRegs N = loadNode(S.nodes + node);
-					if (COUNT) cntNodes++;
-					const float t0 = boxIntersect(N.b0, e, d, false);
-					const float t1 = boxIntersect(N.b1, e, d, false);
-					bool h0 = !(t0 < 0 || t0 > tmin);
-					bool h1 = !(t1 < 0 || t1 > tmin);
-#pragma unroll 1
-					for (int c = 0; c < 2; c++) {   // leaf children are tested on the spot (tmin may shrink in between)
-						const int32_t child = c ? N.c1 : N.c0;
-						const float tb = c ? t1 : t0;
-						if ((c ? h1 : h0) && child < 0 && !(tb > tmin)) testLeaf(~child, c ? N.n1 : N.n0);
-					}
-					h0 = h0 && N.c0 >= 0 && !(t0 > tmin);
-					h1 = h1 && N.c1 >= 0 && !(t1 > tmin);
-					if (h0 && h1) {
-						const bool swap = t1 < t0;
-						if (sp < kStack) stack[sp++][tid] = swap ? N.c0 : N.c1;
-						node = swap ? N.c1 : N.c0;
-					} else if (h0) node = N.c0;
-					else if (h1) node = N.c1;
-					else {
-						if (sp == 0) break;
-						node = stack[--sp][tid];
-					}
-				}
-			}
-		}
-	}
-	best.t = best.prim == RT_NO_HIT ? 0.0f : tmin;
-	return best;
+	} else T.len = length(d);
+	if (S.root_child < 0 && S.root_count == 0) return;
+	const float tr = boxIntersect(S.root_box, e, d, false);   // the root's own box (bvh.cpp:97-100 / 131-134), exact
+	if (tr < 0 || tr > (ANYHIT ? 1.0f : T.tmin)) return;
+	T.cur = S.root_child;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// BVH::calcShadow (bvh.cpp:123-126) + shadowRecursive (bvh.cpp:128-160): any-hit with coloured attenuation.
-// Visiting order is free here (an opaque occluder ends the query whatever came before; the attenuation product
-// commutes), so both children are simply pushed.  Planes are not in the tree and never occlude.
-// ---------------------------------------------------------------------------------------------------------
-template <bool CSG, bool COUNT>
-__device__ __forceinline__ bool shadowTraverse(const DevScene& S, int32_t (*stack)[kBlock], f3 e, f3 d, f3& shadow, unsigned long long& cntNodes, unsigned long long& cntPrims) {
-	const int tid = threadIdx.x;
-	if (S.root_child < 0 && S.root_count == 0) return true;
-	const float len = length(d);
-	bool lit = true;
-
-	auto testLeaf = [&](int32_t first, int32_t count) {   // bvh.cpp:145-157
-		for (int k = 0; k < count && lit; k++) {
-			const uint32_t ref = S.leaf_prims[first + k];
-			uint32_t tag = 0;
-			const float t = primHit<CSG>(S, ref, e, d, tag);
-			if (COUNT) cntPrims++;
-			if (t < 1.0f && (double)(t * len) > 1e-5) {
-				const float* kt = S.materials[primMaterial(S, ref)].transmissive;
-				if (!isZero3(kt)) shadow = shadow * ld3(kt);
-				else lit = false;
-			}
+template <bool ANYHIT, bool CSG, bool COUNT>
+__device__ __forceinline__ void travLeaf(const DevScene& S, Trav& T) {
+	int32_t at = ~T.cur;
+	bool more = true;
+	while (more) {
+		const uint32_t entry = S.leaf_prims[at];
+		const uint32_t ref = entry & ~RT_PRIM_LAST;
+		more = (entry & RT_PRIM_LAST) == 0;
+		uint32_t tag = 0;
+		const float t = primHit<CSG>(S, ref, T.e, T.d, tag);
+		if (COUNT) T.cntPrims++;
+		if (!ANYHIT) {   // bvh.cpp:109-118
+			const uint32_t key = (uint32_t)at + 1u;
+			if ((double)t > 1e-5 && (t < T.tmin || (t == T.tmin && key < T.bestKey))) { T.best = ref; T.bestTag = tag; T.tmin = t; T.bestKey = key; }
+		} else if (t < 1.0f && (double)(t * T.len) > 1e-5) {   // bvh.cpp:145-157
+			const float* kt = S.materials[primMaterial(S, ref)].transmissive;
+			if (!isZero3(kt)) T.shadow = T.shadow * ld3(kt);
+			else { T.lit = false; more = false; }
 		}
-	};
-
-	const float tr = boxIntersect(S.root_box, e, d, false);
-	if (tr < 0 || tr > 1) return true;   // bvh.cpp:133-134
-	if (S.root_child < 0) { testLeaf(~S.root_child, S.root_count); return lit; }
-	int sp = 0;
-	int32_t node = S.root_child;
-	while (true) {
-		const NodeRegs N = loadNode(S.nodes + node);
-		if (COUNT) cntNodes++;
-		const float t0 = boxIntersect(N.b0, e, d, false);
-		const float t1 = boxIntersect(N.b1, e, d, false);
-		bool h0 = !(t0 < 0 || t0 > 1);
-		bool h1 = !(t1 < 0 || t1 > 1);
-#pragma unroll 1
-		for (int c = 0; c < 2; c++) {
-			const int32_t child = c ? N.c1 : N.c0;
-			if ((c ? h1 : h0) && child < 0 && lit) testLeaf(~child, c ? N.n1 : N.n0);
-		}
-		if (!lit) break;
-		h0 = h0 && N.c0 >= 0;
-		h1 = h1 && N.c1 >= 0;
-		if (h0 && h1) { if (sp < kStack) stack[sp++][tid] = N.c1; node = N.c0; }
-		else if (h0) node = N.c0;
-		else if (h1) node = N.c1;
-		else {
-			if (sp == 0) break;
-			node = stack[--sp][tid];
-		}
+		at++;
 	}
-	return lit;
 }
+
+// One round: descend to the next leaf, test it, pick what comes next.  Returns with T.cur == kEmpty when the query is over.
+template <bool ANYHIT, bool CSG, bool COUNT>
+__device__ __forceinline__ void travRound(const DevScene& S, int32_t (*stack)[kBlock], Trav& T) {
+	const int tid = threadIdx.x;
+	while (T.cur >= 0 && T.cur != kEmpty) {
+		const NodeRegs N = loadNode(S.nodes + T.cur);
+		if (COUNT) T.cntNodes++;
+		const float tlimit = ANYHIT ? 1.0f : T.tmin;
+		float t0, t1;
+		int k0 = boxClassify(N.b0, T.e, T.inv, tlimit, t0);
+		int k1 = boxClassify(N.b1, T.e, T.inv, tlimit, t1);
+		if (k0 == 2 || k1 == 2) {   // too close to call with the multiply: the reference's own arithmetic decides
+			if (k0 == 2) { const float t = boxIntersect(N.b0, T.e, T.d, false); k0 = !(t < 0 || t > tlimit); }
+			if (k1 == 2) { const float t = boxIntersect(N.b1, T.e, T.d, false); k1 = !(t < 0 || t > tlimit); }
+		}
+		if (k0 && k1) {
+			const bool swap = !ANYHIT && t1 < t0;
+			if (T.sp < kStack) stack[T.sp++][tid] = swap ? N.c0 : N.c1;
+			T.cur = swap ? N.c1 : N.c0;
+		} else if (k0) T.cur = N.c0;
+		else if (k1) T.cur = N.c1;
+		else T.cur = T.sp > 0 ? stack[--T.sp][tid] : kEmpty;
+	}
+	if (T.cur != kEmpty) {   // a leaf
+		travLeaf<ANYHIT, CSG, COUNT>(S, T);
+		if (ANYHIT && !T.lit) { T.cur = kEmpty; T.sp = 0; }
+		else T.cur = T.sp > 0 ? stack[--T.sp][tid] : kEmpty;
+	}
+}
+
+// Work distribution for the persistent kernels: lanes that have no query ask for the next indices with one atomic
+// per wave.  Returns the lane's index or kInactive; sets `drained` (wave-uniform) once the range is used up.
+__device__ __forceinline__ uint32_t fetchWork(bool need, uint32_t* head, unsigned long long total, bool& drained) {
+	const unsigned long long mask = __ballot(need);
+	if (mask == 0 || drained) return kInactive;
+	const uint32_t lane = __lane_id();
+	const int leader = __ffsll((long long)mask) - 1;
+	const uint32_t cnt = (uint32_t)__popcll(mask);
+	uint32_t base = 0;
+	if ((int)lane == leader) base = atomicAdd(head, cnt);
+	base = __shfl(base, leader);
+	if ((unsigned long long)base + cnt >= total) drained = true;
+	const uint32_t mine = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+	return (need && mine < total) ? mine : kInactive;
+}
+constexpr int kRefillBelow = 48;   // fetch new queries once fewer than this many of the 64 lanes are still busy
 
 // =========================================================================================================
 // kernels
@@ -297,19 +314,40 @@ __global__ __launch_bounds__(kBlock) void k_load_rays(const float* a, const floa
 	qsu(rq, RQ_PATH, i, 1u);
 }
 
+// Persistent nearest-hit kernel: the grid is sized to fill the chip once; every wave keeps pulling rays (fetchWork)
+// and lanes whose ray has finished are refilled while the rest of the wave keeps walking, so one long ray does not
+// idle 63 lanes and the launch has no tail of half-empty waves.
 template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
 	__shared__ int32_t stack[kStack][kBlock];
-	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	if (i >= n) return;
-	if (qu(rq, RQ_PIX, i) == kInactive) { qsu(hq, HQ_PRIM, i, RT_NO_HIT); return; }
-	const f3 e = mk3(qf(rq, RQ_OX, i), qf(rq, RQ_OY, i), qf(rq, RQ_OZ, i));
-	const f3 d = mk3(qf(rq, RQ_DX, i), qf(rq, RQ_DY, i), qf(rq, RQ_DZ, i));
+	uint32_t idx = kInactive;
+	bool drained = false;
+	Trav T;
+	T.cur = kEmpty; T.sp = 0; T.cntNodes = 0; T.cntPrims = 0;
 	unsigned long long cn = 0, cp = 0;
-	const NearestResult r = nearestTraverse<CSG, COUNT>(S, stack, e, d, cn, cp);
-	qsu(hq, HQ_PRIM, i, r.prim);
-	qsf(hq, HQ_T, i, r.t);
-	if (CSG) qsu(hq, HQ_TAG, i, r.tag);
+	for (;;) {
+		const uint32_t got = fetchWork(idx == kInactive, &ctr->head_nearest, n, drained);
+		if (got != kInactive) {
+			idx = got;
+			if (qu(rq, RQ_PIX, idx) == kInactive) { T.cur = kEmpty; T.best = RT_NO_HIT; T.tmin = 0; T.bestTag = 0; }   // padding slot of an edge tile
+			else travInit<false>(S, T, mk3(qf(rq, RQ_OX, idx), qf(rq, RQ_OY, idx), qf(rq, RQ_OZ, idx)), mk3(qf(rq, RQ_DX, idx), qf(rq, RQ_DY, idx), qf(rq, RQ_DZ, idx)));
+		}
+		if (__ballot(idx != kInactive) == 0) break;
+		for (;;) {
+			if (idx != kInactive) {
+				if (T.cur != kEmpty) travRound<false, CSG, COUNT>(S, stack, T);
+				if (T.cur == kEmpty) {   // bvh.cpp:91: return hitObject
+					qsu(hq, HQ_PRIM, idx, T.best);
+					qsf(hq, HQ_T, idx, T.best == RT_NO_HIT ? 0.0f : T.tmin);
+					if (CSG) qsu(hq, HQ_TAG, idx, T.bestTag);
+					if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
+					idx = kInactive;
+				}
+			}
+			const int busy = __popcll(__ballot(idx != kInactive));
+			if (busy == 0 || (!drained && busy < kRefillBelow)) break;
+		}
+	}
 	if (COUNT) { atomicAdd(&ctr->nodes_nearest, cn); atomicAdd(&ctr->prims_nearest, cp); }
 }
 
@@ -524,33 +562,62 @@ __device__ __forceinline__ Surface loadSurface(const RtQueue& sq, uint32_t s) {
 	return r;
 }
 
-// Directional / Point / Spot lights: one shadow ray per (surface, light); consecutive lanes take consecutive
-// surfaces of the SAME light so a wave's rays share their target.
+// Directional / Point / Spot lights: one shadow ray per (surface, light); consecutive work items are consecutive
+// surfaces of the SAME light so a wave's rays share their target.  Persistent with lane refill like k_intersect.
+__device__ __forceinline__ void pointLightGeometry(const rt_light& L, f3 p, f3& Ld, f3& lightPos) {
+	if (L.type == RT_LIGHT_DIRECTIONAL) {   // objects.cpp:399-410
+		Ld = -ld3(L.direction);
+		lightPos = p + RT_MAX_T * Ld;
+	} else {
+		lightPos = ld3(L.position);   // objects.cpp:422-431, 445-458
+		Ld = normalize(lightPos - p);
+	}
+}
+
 template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                                                          RtAccum A, uint32_t aaSq, RtCounters* ctr) {
 	__shared__ int32_t stack[kStack][kBlock];
-	const unsigned long long j = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
-	if (j >= (unsigned long long)nsurf * nLights) return;
-	const uint32_t s = (uint32_t)(j % nsurf);
-	const rt_light L = S.lights[lightList[j / nsurf]];
-	const Surface sf = loadSurface(sq, s);
-	f3 Ld, lightPos;
-	if (L.type == RT_LIGHT_DIRECTIONAL) {   // objects.cpp:399-410
-		Ld = -ld3(L.direction);
-		lightPos = sf.p + RT_MAX_T * Ld;
-	} else {
-		lightPos = ld3(L.position);   // objects.cpp:422-431, 445-458
-		Ld = normalize(lightPos - sf.p);
-	}
-	f3 shadow = mk3(1.0f, 1.0f, 1.0f);
+	const unsigned long long total = (unsigned long long)nsurf * nLights;
+	uint32_t idx = kInactive;
+	bool drained = false;
+	Trav T;
+	T.cur = kEmpty; T.sp = 0; T.cntNodes = 0; T.cntPrims = 0; T.lit = true; T.shadow = mk3(1.0f, 1.0f, 1.0f);
 	unsigned long long cn = 0, cp = 0;
-	const bool lit = shadowTraverse<CSG, COUNT>(S, stack, sf.p, lightPos - sf.p, shadow, cn, cp);
+	for (;;) {
+		const uint32_t got = fetchWork(idx == kInactive, &ctr->head_shadow, total, drained);
+		if (got != kInactive) {
+			idx = got;
+			const uint32_t s = idx % nsurf;
+			const f3 p = mk3(qf(sq, SQ_PX, s), qf(sq, SQ_PY, s), qf(sq, SQ_PZ, s));
+			f3 Ld, lightPos;
+			pointLightGeometry(S.lights[lightList[idx / nsurf]], p, Ld, lightPos);
+			travInit<true>(S, T, p, lightPos - p);   // bvh.cpp:124
+		}
+		if (__ballot(idx != kInactive) == 0) break;
+		for (;;) {
+			if (idx != kInactive) {
+				if (T.cur != kEmpty) travRound<true, CSG, COUNT>(S, stack, T);
+				if (T.cur == kEmpty) {
+					if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
+					if (T.lit) {
+						const rt_light L = S.lights[lightList[idx / nsurf]];
+						const Surface sf = loadSurface(sq, idx % nsurf);
+						f3 Ld, lightPos;
+						pointLightGeometry(L, sf.p, Ld, lightPos);
+						if (!(L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff))) {   // objects.cpp:451
+							const f3 c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
+							accumAdd(A, sf.pixKey / aaSq, sf.w * c);
+						}
+					}
+					idx = kInactive;
+				}
+			}
+			const int busy = __popcll(__ballot(idx != kInactive));
+			if (busy == 0 || (!drained && busy < kRefillBelow)) break;
+		}
+	}
 	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
-	if (!lit) return;
-	if (L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff)) return;   // objects.cpp:451
-	const f3 c = phong(ld3(L.colour) * shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
-	accumAdd(A, sf.pixKey / aaSq, sf.w * c);
 }
 
 // Rectangular / circular area light `lightIndex`: one lane per (surface, sample), samples of one surface in
@@ -585,11 +652,11 @@ __global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, 
 			yDisplacement = displacement * sinf(angle);
 		}
 		const f3 lightPos = ld3(L.position) + ld3(L.planeX) * xDisplacement + ld3(L.planeY) * yDisplacement;
-		f3 shadow = mk3(1.0f, 1.0f, 1.0f);
-		unsigned long long cn = 0, cp = 0;
-		const bool lit = shadowTraverse<CSG, COUNT>(S, stack, sf.p, lightPos - sf.p, shadow, cn, cp);
-		if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
-		if (lit) c = phong(ld3(L.colour) * shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
+		Trav T;
+		travInit<true>(S, T, sf.p, lightPos - sf.p);
+		while (T.cur != kEmpty) travRound<true, CSG, COUNT>(S, stack, T);
+		if (COUNT) { atomicAdd(&ctr->nodes_shadow, T.cntNodes); atomicAdd(&ctr->prims_shadow, T.cntPrims); }
+		if (T.lit) c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
 	}
 	// segmented inclusive scan over the wave, key = surface
 	const uint32_t lane = __lane_id();
@@ -610,11 +677,11 @@ __global__ __launch_bounds__(kBlock) void k_shadow_query(DevScene S, const float
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n) return;
 	const f3 p = ld3(point + 3 * (size_t)i), l = ld3(lightPos + 3 * (size_t)i);
-	f3 shadow = mk3(1.0f, 1.0f, 1.0f);
-	unsigned long long cn = 0, cp = 0;
-	const bool ok = shadowTraverse<CSG, false>(S, stack, p, l - p, shadow, cn, cp);   // bvh.cpp:124
-	if (lit) lit[i] = ok;
-	if (shadowOut) { shadowOut[3 * (size_t)i] = shadow.x; shadowOut[3 * (size_t)i + 1] = shadow.y; shadowOut[3 * (size_t)i + 2] = shadow.z; }
+	Trav T;
+	travInit<true>(S, T, p, l - p);   // bvh.cpp:124
+	while (T.cur != kEmpty) travRound<true, CSG, false>(S, stack, T);
+	if (lit) lit[i] = T.lit;
+	if (shadowOut) { shadowOut[3 * (size_t)i] = T.shadow.x; shadowOut[3 * (size_t)i + 1] = T.shadow.y; shadowOut[3 * (size_t)i + 2] = T.shadow.z; }
 }
 
 // fixed point -> float RGB for the pixels of local range [lp0, lp0+count); clears the accumulators for the next frame
@@ -655,6 +722,8 @@ __global__ __launch_bounds__(kBlock) void k_tiles_copy(const float* src, float* 
 }
 
 inline unsigned gridFor(unsigned long long n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+// persistent kernels: enough workgroups to fill every CU once (the kernels loop over the work themselves)
+inline unsigned gridPersistent(unsigned long long n, int maxBlocks) { return (unsigned)std::min<unsigned long long>((n + kBlock - 1) / kBlock, (unsigned long long)maxBlocks); }
 
 }  // namespace
 
@@ -662,6 +731,7 @@ inline unsigned gridFor(unsigned long long n) { return (unsigned)((n + kBlock - 
 // launch wrappers (host)
 // =========================================================================================================
 #define RT_LAUNCH(kernel, n, stream, ...) do { if ((n) > 0) hipLaunchKernelGGL(kernel, dim3(gridFor(n)), dim3(kBlock), 0, stream, __VA_ARGS__); } while (0)
+#define RT_LAUNCH_P(kernel, n, maxBlocks, stream, ...) do { if ((n) > 0) hipLaunchKernelGGL(kernel, dim3(gridPersistent(n, maxBlocks)), dim3(kBlock), 0, stream, __VA_ARGS__); } while (0)
 
 void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, int aaY, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq) {
 	RT_LAUNCH(k_generate, count, st, cam, W, H, aaX, aaY, tileRank, tileRanks, r0, count, rq);
@@ -669,9 +739,9 @@ void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, i
 void rtk_load_rays(hipStream_t st, const float* a, const float* b, uint32_t n, int bIsTarget, RtQueue rq, uint32_t pixBase) {
 	RT_LAUNCH(k_load_rays, n, st, a, b, n, bIsTarget, rq, pixBase);
 }
-void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
-	if (csg) { if (count) RT_LAUNCH((k_intersect<true, true>), n, st, S, rq, n, hq, ctr); else RT_LAUNCH((k_intersect<true, false>), n, st, S, rq, n, hq, ctr); }
-	else { if (count) RT_LAUNCH((k_intersect<false, true>), n, st, S, rq, n, hq, ctr); else RT_LAUNCH((k_intersect<false, false>), n, st, S, rq, n, hq, ctr); }
+void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
+	if (csg) { if (count) RT_LAUNCH_P((k_intersect<true, true>), n, maxBlocks, st, S, rq, n, hq, ctr); else RT_LAUNCH_P((k_intersect<true, false>), n, maxBlocks, st, S, rq, n, hq, ctr); }
+	else { if (count) RT_LAUNCH_P((k_intersect<false, true>), n, maxBlocks, st, S, rq, n, hq, ctr); else RT_LAUNCH_P((k_intersect<false, false>), n, maxBlocks, st, S, rq, n, hq, ctr); }
 }
 void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, uint8_t* hit, int32_t* id, float* t) {
 	RT_LAUNCH(k_export_hits, n, st, S, hq, n, hit, id, t);
@@ -681,11 +751,11 @@ void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue 
 	if (csg) RT_LAUNCH((k_shade<true>), n, st, S, rq, hq, n, nq, sq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT);
 	else RT_LAUNCH((k_shade<false>), n, st, S, rq, hq, n, nq, sq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT);
 }
-void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
+void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                       RtAccum A, uint32_t aaSq, RtCounters* ctr) {
 	const unsigned long long items = (unsigned long long)nsurf * nLights;
-	if (csg) { if (count) RT_LAUNCH((k_shadow_point<true, true>), items, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH((k_shadow_point<true, false>), items, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
-	else { if (count) RT_LAUNCH((k_shadow_point<false, true>), items, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH((k_shadow_point<false, false>), items, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
+	if (csg) { if (count) RT_LAUNCH_P((k_shadow_point<true, true>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_P((k_shadow_point<true, false>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
+	else { if (count) RT_LAUNCH_P((k_shadow_point<false, true>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_P((k_shadow_point<false, false>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
 }
 void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t samples, uint32_t seed,
                      RtAccum A, uint32_t aaSq, RtCounters* ctr) {

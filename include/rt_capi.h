@@ -48,7 +48,7 @@ typedef struct rt_stats {
 	float    gpu_ms;           /* hipEvent time of the whole call on `stream`, upload/download excluded */
 	float    nearest_ms;       /* hipEvent time spent in the nearest-hit traversal kernel (dominant kernel) */
 	float    shadow_ms;        /* hipEvent time spent in the shadow traversal kernel */
-	float    pad;
+	float    max_walk;         /* longest nearest-hit walk of the call in nodes (only when RT_FLAG_COUNTERS) */
 } rt_stats;
 
 #define RT_FLAG_COUNTERS   1u   /* count nodes / primitive tests in the traversal kernels (slower) */

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libraytracer_amd.so")
+LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(_HERE, "lib", "libraytracer_amd.so")   # RT_LIB_PATH: diagnostic builds
 
 RT_OK, RT_EINVAL, RT_EIO, RT_EPARSE, RT_EHIP, RT_ENOMEM, RT_ELIMIT = 0, -1, -2, -3, -4, -5, -6
 RT_FLAG_COUNTERS, RT_FLAG_TIME_KERNELS = 1, 2
@@ -38,7 +38,7 @@ class rt_stats(C.Structure):
     _fields_ = [("rays_nearest", C.c_uint64), ("rays_shadow", C.c_uint64), ("nodes_nearest", C.c_uint64), ("prims_nearest", C.c_uint64),
                 ("nodes_shadow", C.c_uint64), ("prims_shadow", C.c_uint64),
                 ("levels", C.c_uint64), ("batch_splits", C.c_uint64), ("gpu_ms", C.c_float), ("nearest_ms", C.c_float),
-                ("shadow_ms", C.c_float), ("pad", C.c_float)]
+                ("shadow_ms", C.c_float), ("max_walk", C.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}

@@ -104,6 +104,11 @@ struct Run {
 	rt_scene* sc; hipStream_t st; Source src; int maxDepth; uint32_t seed; uint32_t flags; uint32_t aaSq;
 	rt_stats stats{};
 
+	// Which traversal form a level uses.  Level 0 of a frame (and its shadow rays) is coherent by construction: 64
+	// consecutive queue slots are an 8x8 pixel block.  Deeper levels and caller-supplied rays are walked per lane.
+	int packetLevels = 1;
+	bool coherent(int level) const { return src.camera && level < packetLevels; }
+
 	int syncCounters() {
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(sc->ctrHost, sc->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost, st));
@@ -123,7 +128,7 @@ struct Run {
 		for (int level = 0; level <= maxDepth && n > 0; level++) {
 			HIPCHK(hipMemsetAsync(sc->ctr, 0, 4 * sizeof(uint32_t), st));   // next_count, surf_count, head_nearest, head_shadow
 			if (timeK) HIPCHK(hipEventRecord(sc->ev[2], st));
-			rtk_intersect(st, sc->dev, sc->hasCsg, count, sc->maxBlocks, sc->ray[cur], n, sc->hitq, sc->ctr);
+			rtk_intersect(st, sc->dev, sc->hasCsg, count, coherent(level), sc->maxBlocks, sc->ray[cur], n, sc->hitq, sc->ctr);
 			if (timeK) HIPCHK(hipEventRecord(sc->ev[3], st));
 			rtk_shade(st, sc->dev, sc->hasCsg, sc->ray[cur], sc->hitq, n, sc->ray[cur ^ 1], sc->surfq, sc->ctr, sc->accum, aaSq, maxDepth,
 			          sc->shadowRaysPerSurface > 0, level == 0 ? src.outHit : nullptr, src.outId, src.outT);
@@ -140,7 +145,7 @@ struct Run {
 			const uint32_t nsurf = sc->ctrHost->surf_count;
 			if (nsurf > 0 && sc->shadowRaysPerSurface > 0) {
 				if (timeK) HIPCHK(hipEventRecord(sc->ev[4], st));
-				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, sc->maxBlocks, sc->surfq, nsurf, sc->pointLights, sc->nPointLights, sc->accum, aaSq, sc->ctr);
+				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, coherent(level), sc->maxBlocks, sc->surfq, nsurf, sc->pointLights, sc->nPointLights, sc->accum, aaSq, sc->ctr);
 				for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, count, sc->surfq, nsurf, al.first, al.second, seed, sc->accum, aaSq, sc->ctr);
 				if (timeK) { HIPCHK(hipEventRecord(sc->ev[5], st)); shadowPending = true; }
 				shadowRays += (uint64_t)nsurf * sc->shadowRaysPerSurface;
@@ -198,6 +203,7 @@ int finish(rt_scene* sc, hipStream_t st, Run& run, rt_stats* stats) {
 	if (run.flags & RT_FLAG_COUNTERS) {
 		run.stats.nodes_nearest = sc->ctrHost->nodes_nearest; run.stats.prims_nearest = sc->ctrHost->prims_nearest;
 		run.stats.nodes_shadow = sc->ctrHost->nodes_shadow; run.stats.prims_shadow = sc->ctrHost->prims_shadow;
+		run.stats.max_walk = (float)sc->ctrHost->pad;   // longest nearest-hit walk of the call, in nodes (diagnostic)
 	}
 	if (stats) *stats = run.stats;
 	return RT_OK;
@@ -400,7 +406,7 @@ int rt_intersect_batch(rt_scene* sc, const float* e, const float* d, size_t n, u
 		const uint32_t cnt = (uint32_t)std::min<size_t>(sc->qcap, n - c0);
 		HIPCHK(hipMemsetAsync(sc->ctr, 0, 4 * sizeof(uint32_t), st));
 		rtk_load_rays(st, de.as<float>() + 3 * c0, dd.as<float>() + 3 * c0, cnt, 0, sc->ray[0], 0);
-		rtk_intersect(st, sc->dev, sc->hasCsg, (flags & RT_FLAG_COUNTERS) != 0, sc->maxBlocks, sc->ray[0], cnt, sc->hitq, sc->ctr);
+		rtk_intersect(st, sc->dev, sc->hasCsg, (flags & RT_FLAG_COUNTERS) != 0, false, sc->maxBlocks, sc->ray[0], cnt, sc->hitq, sc->ctr);
 		rtk_export_hits(st, sc->dev, sc->hitq, cnt, dhit.as<uint8_t>() + c0, did.as<int32_t>() + c0, dt.as<float>() + c0);
 		run.stats.rays_nearest += cnt;
 	}

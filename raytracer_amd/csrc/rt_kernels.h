@@ -6,6 +6,9 @@
 #include "rt_device.h"
 
 #define RT_BLOCK 256          /* threads per workgroup = 4 wavefronts */
+#ifndef RT_REFILL_BELOW
+#define RT_REFILL_BELOW 48
+#endif
 #define RT_STACK_DEPTH 20     /* per-lane traversal stack entries in LDS (20 x 256 x 4 B = 20 KB per workgroup);
                                  a nearer-child-first walk of a binary tree needs at most its depth, and the
                                  reference's build stops at depth 16 (bvh.h:6); checked at upload */
@@ -35,11 +38,11 @@ using rtd::DevScene;
 
 void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, int aaY, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq);
 void rtk_load_rays(hipStream_t st, const float* a, const float* b, uint32_t n, int bIsTarget, RtQueue rq, uint32_t pixBase);
-void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr);
+void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr);
 void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, uint8_t* hit, int32_t* id, float* t);
 void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtCounters* ctr, RtAccum A,
                uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT);
-void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
+void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                       RtAccum A, uint32_t aaSq, RtCounters* ctr);
 void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t samples, uint32_t seed,
                      RtAccum A, uint32_t aaSq, RtCounters* ctr);

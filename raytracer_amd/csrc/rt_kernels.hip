@@ -260,22 +260,163 @@ __device__ __forceinline__ void travRound(const DevScene& S, int32_t (*stack)[kB
 	}
 }
 
-// Work distribution for the persistent kernels: lanes that have no query ask for the next indices with one atomic
-// per wave.  Returns the lane's index or kInactive; sets `drained` (wave-uniform) once the range is used up.
-__device__ __forceinline__ uint32_t fetchWork(bool need, uint32_t* head, unsigned long long total, bool& drained) {
-	const unsigned long long mask = __ballot(need);
-	if (mask == 0 || drained) return kInactive;
-	const uint32_t lane = __lane_id();
-	const int leader = __ffsll((long long)mask) - 1;
-	const uint32_t cnt = (uint32_t)__popcll(mask);
-	uint32_t base = 0;
-	if ((int)lane == leader) base = atomicAdd(head, cnt);
-	base = __shfl(base, leader);
-	if ((unsigned long long)base + cnt >= total) drained = true;
-	const uint32_t mine = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-	return (need && mine < total) ? mine : kInactive;
+// ---------------------------------------------------------------------------------------------------------
+// Packet traversal for COHERENT rays (camera rays of an 8x8 pixel block, their shadow rays to one light, the samples
+// of one area light from one surface point).
+//
+// Measured on MI355X (tools/ubench/gather*.hip, profiles/): a wave whose 64 lanes each fetch their own 64 B node
+// costs the CU's vector-memory pipeline ~340 cycles per step whatever the occupancy -- per-lane walks are bound by
+// that pipeline, not by arithmetic or HBM.  A packet walks the UNION of its rays' subtrees instead: the node index is
+// wave-uniform, so nodes, leaf entries and triangle records come through the scalar cache (s_load) and the vector
+// memory pipeline is not used at all; each lane still applies the reference's tests to its own ray, and only to
+// nodes whose parent box its own ray passed (the lane mask travels with every stack entry), so every lane tests
+// exactly the primitives its own per-lane walk would test.  The stack is one entry per WAVE, not per lane.
+// ---------------------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(4))) const v4f cfloat4;   // constant address space + wave-uniform address => s_load
+typedef __attribute__((address_space(4))) const v2f cfloat2;
+typedef __attribute__((address_space(4))) const uint32_t cuint32;
+
+__device__ __forceinline__ NodeRegs sloadNode(const rt_bvh_node* nodes, int32_t node) {   // node must be wave-uniform
+	cfloat4* q = (cfloat4*)(uintptr_t)(nodes + node);
+	const v4f a = q[0], b = q[1], c = q[2];
+	const v2f d = *(cfloat2*)(uintptr_t)(reinterpret_cast<const float4*>(nodes + node) + 3);
+	NodeRegs r;
+	r.b0[0] = a.x; r.b0[1] = a.y; r.b0[2] = a.z; r.b0[3] = a.w; r.b0[4] = b.x; r.b0[5] = b.y;
+	r.b1[0] = b.z; r.b1[1] = b.w; r.b1[2] = c.x; r.b1[3] = c.y; r.b1[4] = c.z; r.b1[5] = c.w;
+	r.c0 = __float_as_int(d.x); r.c1 = __float_as_int(d.y);
+	return r;
 }
-constexpr int kRefillBelow = 48;   // fetch new queries once fewer than this many of the 64 lanes are still busy
+
+// object->rayhit(e, d) with a wave-uniform primitive reference: the record is fetched once per wave (scalar loads)
+template <bool CSG>
+__device__ __forceinline__ float primHitUniform(const DevScene& S, uint32_t ref, f3 e, f3 d, uint32_t& tag) {
+	const uint32_t ix = RT_PRIM_INDEX(ref);
+	const uint32_t ty = RT_PRIM_TYPE(ref);
+	if (ty == RT_PRIM_TRI) {
+		cfloat4* q = (cfloat4*)(uintptr_t)(S.tris + ix);
+		const v4f a = q[0], b = q[1], c = q[2];
+		return triHit(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), e, d, false);
+	}
+	if (ty == RT_PRIM_SPHERE) {
+		const v4f s = *(cfloat4*)(uintptr_t)(S.spheres + ix);
+		return sphereHit(mk3(s.x, s.y, s.z), s.w, e, d, false);
+	}
+	if (ty == RT_PRIM_BOX) {
+		const v4f a = *(cfloat4*)(uintptr_t)(S.boxes + ix);
+		const v2f b = *(cfloat2*)(uintptr_t)(S.boxes[ix].b + 4);
+		const float bb[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
+		return boxHit(bb, e, d, false);
+	}
+	if (CSG) return csgEval(S, S.csgs[ix], e, d, false, tag);
+	return 0.0f;
+}
+
+// `alive`: the lane holds a query.  T must come from travInit (T.cur == kEmpty: the lane's ray missed the root box).
+// wstack: this wave's kStack x 3 dwords of LDS.
+template <bool ANYHIT, bool CSG, bool COUNT>
+__device__ __forceinline__ void packetTraverse(const DevScene& S, uint32_t* wstack, Trav& T, bool alive) {
+	const uint32_t lane = __lane_id();
+	bool inSub = alive && T.cur != kEmpty;   // this lane's ray passed the box of the current node
+	if (__ballot(inSub) == 0) return;
+	int32_t node = S.root_child;
+	int sp = 0;
+	for (;;) {
+		node = __builtin_amdgcn_readfirstlane(node);
+		bool popNext = true;
+		if (node >= 0) {
+			const NodeRegs N = sloadNode(S.nodes, node);
+			int k0 = 0, k1 = 0;
+			float t0 = 0, t1 = 0;
+			if (inSub) {
+				if (COUNT) T.cntNodes++;
+				const float tlimit = ANYHIT ? 1.0f : T.tmin;
+				k0 = boxClassify(N.b0, T.e, T.inv, tlimit, t0);
+				k1 = boxClassify(N.b1, T.e, T.inv, tlimit, t1);
+				if (k0 == 2) { const float t = boxIntersect(N.b0, T.e, T.d, false); k0 = !(t < 0 || t > tlimit); }
+				if (k1 == 2) { const float t = boxIntersect(N.b1, T.e, T.d, false); k1 = !(t < 0 || t > tlimit); }
+			}
+			const unsigned long long m0 = __ballot(k0 != 0), m1 = __ballot(k1 != 0);
+			if (m0 != 0 && m1 != 0) {
+				// visit first the child most rays reach first (any order is correct; ties go to the reference's order by key)
+				const unsigned long long both = m0 & m1;
+				const bool swap = !ANYHIT && 2 * __popcll(__ballot(k0 && k1 && t1 < t0)) > __popcll(both);
+				const unsigned long long mFar = swap ? m0 : m1;
+				if (sp < kStack) {
+					wstack[3 * sp] = (uint32_t)(swap ? N.c0 : N.c1);
+					wstack[3 * sp + 1] = (uint32_t)mFar; wstack[3 * sp + 2] = (uint32_t)(mFar >> 32);
+					sp++;
+				}
+				node = swap ? N.c1 : N.c0;
+				inSub = swap ? k1 != 0 : k0 != 0;
+				popNext = false;
+			} else if (m0 != 0) { node = N.c0; inSub = k0 != 0; popNext = false; }
+			else if (m1 != 0) { node = N.c1; inSub = k1 != 0; popNext = false; }
+		} else {   // leaf: bvh.cpp:109-118 / 145-157 for the lanes whose ray passed this leaf's box
+			int32_t at = ~node;
+			for (;;) {
+				const uint32_t entry = *(cuint32*)(uintptr_t)(S.leaf_prims + at);
+				const uint32_t ref = entry & ~RT_PRIM_LAST;
+				if (inSub && (!ANYHIT || T.lit)) {
+					uint32_t tag = 0;
+					const float t = primHitUniform<CSG>(S, ref, T.e, T.d, tag);
+					if (COUNT) T.cntPrims++;
+					if (!ANYHIT) {
+						const uint32_t key = (uint32_t)at + 1u;
+						if ((double)t > 1e-5 && (t < T.tmin || (t == T.tmin && key < T.bestKey))) { T.best = ref; T.bestTag = tag; T.tmin = t; T.bestKey = key; }
+					} else if (t < 1.0f && (double)(t * T.len) > 1e-5) {
+						const float* kt = S.materials[primMaterial(S, ref)].transmissive;
+						if (!isZero3(kt)) T.shadow = T.shadow * ld3(kt);
+						else T.lit = false;
+					}
+				}
+				if (entry & RT_PRIM_LAST) break;
+				at++;
+			}
+		}
+		if (popNext) {
+			for (;;) {
+				if (sp == 0) return;
+				sp--;
+				const unsigned long long m = (unsigned long long)wstack[3 * sp + 1] | ((unsigned long long)wstack[3 * sp + 2] << 32);
+				node = (int32_t)wstack[3 * sp];
+				inSub = ((m >> lane) & 1ull) != 0 && (!ANYHIT || T.lit);
+				if (__ballot(inSub) != 0) break;   // nobody left who wants this subtree (occluded lanes)
+			}
+		}
+	}
+}
+
+// Work distribution for the persistent kernels.  A single device-wide cursor saturates at roughly 90 returning
+// atomics per microsecond (MI355X_MICROARCH.md, row "dequeue"), and one atomic per lane refill made that cursor the
+// bottleneck of the whole launch.  Each wave therefore takes kWorkChunk consecutive indices per atomic into a
+// wave-local pool and refills its idle lanes from the pool.
+constexpr uint32_t kWorkChunk = 128;
+struct WorkPool { uint32_t next, end; bool drained; };
+
+__device__ __forceinline__ uint32_t fetchWork(bool need, WorkPool& pool, uint32_t* head, unsigned long long total) {
+	const unsigned long long mask = __ballot(need);
+	if (mask == 0) return kInactive;
+	if (pool.next == pool.end && !pool.drained) {   // wave-uniform
+		uint32_t base = 0;
+		if (__lane_id() == 0) base = atomicAdd(head, kWorkChunk);
+		base = __builtin_amdgcn_readfirstlane(base);
+		if ((unsigned long long)base >= total) pool.drained = true;
+		else {
+			pool.next = base;
+			pool.end = (uint32_t)((unsigned long long)base + kWorkChunk < total ? base + kWorkChunk : total);
+		}
+	}
+	const uint32_t avail = pool.end - pool.next;
+	const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << __lane_id()) - 1ull));
+	const uint32_t mine = (need && rank < avail) ? pool.next + rank : kInactive;
+	const uint32_t cnt = (uint32_t)__popcll(mask);
+	pool.next += cnt < avail ? cnt : avail;
+	return mine;
+}
+__device__ __forceinline__ bool workLeft(const WorkPool& pool) { return !pool.drained || pool.next != pool.end; }
+constexpr int kRefillBelow = RT_REFILL_BELOW;   // fetch new queries once fewer than this many of the 64 lanes are still busy
 
 // =========================================================================================================
 // kernels
@@ -321,18 +462,18 @@ template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
 	__shared__ int32_t stack[kStack][kBlock];
 	uint32_t idx = kInactive;
-	bool drained = false;
+	WorkPool pool = { 0u, 0u, false };
 	Trav T;
 	T.cur = kEmpty; T.sp = 0; T.cntNodes = 0; T.cntPrims = 0;
 	unsigned long long cn = 0, cp = 0;
 	for (;;) {
-		const uint32_t got = fetchWork(idx == kInactive, &ctr->head_nearest, n, drained);
+		const uint32_t got = fetchWork(idx == kInactive, pool, &ctr->head_nearest, n);
 		if (got != kInactive) {
 			idx = got;
 			if (qu(rq, RQ_PIX, idx) == kInactive) { T.cur = kEmpty; T.best = RT_NO_HIT; T.tmin = 0; T.bestTag = 0; }   // padding slot of an edge tile
 			else travInit<false>(S, T, mk3(qf(rq, RQ_OX, idx), qf(rq, RQ_OY, idx), qf(rq, RQ_OZ, idx)), mk3(qf(rq, RQ_DX, idx), qf(rq, RQ_DY, idx), qf(rq, RQ_DZ, idx)));
 		}
-		if (__ballot(idx != kInactive) == 0) break;
+		if (__ballot(idx != kInactive) == 0) { if (workLeft(pool)) continue; break; }
 		for (;;) {
 			if (idx != kInactive) {
 				if (T.cur != kEmpty) travRound<false, CSG, COUNT>(S, stack, T);
@@ -340,13 +481,41 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RtQueue rq, ui
 					qsu(hq, HQ_PRIM, idx, T.best);
 					qsf(hq, HQ_T, idx, T.best == RT_NO_HIT ? 0.0f : T.tmin);
 					if (CSG) qsu(hq, HQ_TAG, idx, T.bestTag);
-					if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
+					if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; atomicMax(&ctr->pad, (uint32_t)T.cntNodes); }
 					idx = kInactive;
 				}
 			}
 			const int busy = __popcll(__ballot(idx != kInactive));
-			if (busy == 0 || (!drained && busy < kRefillBelow)) break;
+			if (busy == 0 || (workLeft(pool) && busy < kRefillBelow)) break;
 		}
+	}
+	if (COUNT) { atomicAdd(&ctr->nodes_nearest, cn); atomicAdd(&ctr->prims_nearest, cp); }
+}
+
+// Nearest hit for coherent ray sets: one packet = 64 consecutive queue slots (an 8x8 pixel block of the tile order).
+template <bool CSG, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_intersect_packet(DevScene S, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
+	__shared__ uint32_t wstack[kBlock / 64][kStack * 3];
+	const uint32_t lane = __lane_id();
+	uint32_t* ws = wstack[threadIdx.x >> 6];
+	unsigned long long cn = 0, cp = 0;
+	for (;;) {
+		uint32_t base = 0;
+		if (lane == 0) base = atomicAdd(&ctr->head_nearest, 64u);
+		base = __builtin_amdgcn_readfirstlane(base);
+		if (base >= n) break;
+		const uint32_t idx = base + lane;
+		const bool alive = idx < n && qu(rq, RQ_PIX, idx < n ? idx : base) != kInactive;
+		Trav T;
+		T.cur = kEmpty; T.best = RT_NO_HIT; T.tmin = 0; T.bestTag = 0; T.cntNodes = 0; T.cntPrims = 0;
+		if (alive) travInit<false>(S, T, mk3(qf(rq, RQ_OX, idx), qf(rq, RQ_OY, idx), qf(rq, RQ_OZ, idx)), mk3(qf(rq, RQ_DX, idx), qf(rq, RQ_DY, idx), qf(rq, RQ_DZ, idx)));
+		packetTraverse<false, CSG, COUNT>(S, ws, T, alive);
+		if (idx < n) {
+			qsu(hq, HQ_PRIM, idx, alive ? T.best : RT_NO_HIT);
+			qsf(hq, HQ_T, idx, (alive && T.best != RT_NO_HIT) ? T.tmin : 0.0f);
+			if (CSG) qsu(hq, HQ_TAG, idx, T.bestTag);
+		}
+		if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
 	}
 	if (COUNT) { atomicAdd(&ctr->nodes_nearest, cn); atomicAdd(&ctr->prims_nearest, cp); }
 }
@@ -580,12 +749,12 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq,
 	__shared__ int32_t stack[kStack][kBlock];
 	const unsigned long long total = (unsigned long long)nsurf * nLights;
 	uint32_t idx = kInactive;
-	bool drained = false;
+	WorkPool pool = { 0u, 0u, false };
 	Trav T;
 	T.cur = kEmpty; T.sp = 0; T.cntNodes = 0; T.cntPrims = 0; T.lit = true; T.shadow = mk3(1.0f, 1.0f, 1.0f);
 	unsigned long long cn = 0, cp = 0;
 	for (;;) {
-		const uint32_t got = fetchWork(idx == kInactive, &ctr->head_shadow, total, drained);
+		const uint32_t got = fetchWork(idx == kInactive, pool, &ctr->head_shadow, total);
 		if (got != kInactive) {
 			idx = got;
 			const uint32_t s = idx % nsurf;
@@ -594,7 +763,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq,
 			pointLightGeometry(S.lights[lightList[idx / nsurf]], p, Ld, lightPos);
 			travInit<true>(S, T, p, lightPos - p);   // bvh.cpp:124
 		}
-		if (__ballot(idx != kInactive) == 0) break;
+		if (__ballot(idx != kInactive) == 0) { if (workLeft(pool)) continue; break; }
 		for (;;) {
 			if (idx != kInactive) {
 				if (T.cur != kEmpty) travRound<true, CSG, COUNT>(S, stack, T);
@@ -614,7 +783,44 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq,
 				}
 			}
 			const int busy = __popcll(__ballot(idx != kInactive));
-			if (busy == 0 || (!drained && busy < kRefillBelow)) break;
+			if (busy == 0 || (workLeft(pool) && busy < kRefillBelow)) break;
+		}
+	}
+	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
+}
+
+// Packet form of k_shadow_point for coherent surface sets: 64 consecutive surfaces towards the same light.
+template <bool CSG, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_shadow_point_packet(DevScene S, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
+                                                                RtAccum A, uint32_t aaSq, RtCounters* ctr) {
+	__shared__ uint32_t wstack[kBlock / 64][kStack * 3];
+	const uint32_t lane = __lane_id();
+	uint32_t* ws = wstack[threadIdx.x >> 6];
+	const uint32_t packetsPerLight = (nsurf + 63u) / 64u;
+	const uint32_t totalPackets = packetsPerLight * nLights;
+	unsigned long long cn = 0, cp = 0;
+	for (;;) {
+		uint32_t pk = 0;
+		if (lane == 0) pk = atomicAdd(&ctr->head_shadow, 1u);
+		pk = __builtin_amdgcn_readfirstlane(pk);
+		if (pk >= totalPackets) break;
+		const rt_light L = S.lights[lightList[pk / packetsPerLight]];
+		const uint32_t s = (pk % packetsPerLight) * 64u + lane;
+		const bool alive = s < nsurf;
+		Trav T;
+		T.cur = kEmpty; T.lit = true; T.shadow = mk3(1.0f, 1.0f, 1.0f); T.cntNodes = 0; T.cntPrims = 0;
+		Surface sf;
+		f3 Ld = mk3(0, 0, 0), lightPos = Ld;
+		if (alive) {
+			sf = loadSurface(sq, s);
+			pointLightGeometry(L, sf.p, Ld, lightPos);
+			travInit<true>(S, T, sf.p, lightPos - sf.p);   // bvh.cpp:124
+		}
+		packetTraverse<true, CSG, COUNT>(S, ws, T, alive);
+		if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
+		if (alive && T.lit && !(L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff))) {   // objects.cpp:451
+			const f3 c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
+			accumAdd(A, sf.pixKey / aaSq, sf.w * c);
 		}
 	}
 	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
@@ -626,7 +832,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq,
 template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t seed,
                                                         RtAccum A, uint32_t aaSq, RtCounters* ctr) {
-	__shared__ int32_t stack[kStack][kBlock];
+	__shared__ uint32_t wstack[kBlock / 64][kStack * 3];
 	const rt_light L = S.lights[lightIndex];
 	const uint32_t ns = (uint32_t)L.samples;
 	const unsigned long long j = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
@@ -635,6 +841,9 @@ __global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, 
 	f3 c = mk3(0, 0, 0);
 	Surface sf;
 	sf.w = c; sf.pixKey = 0;
+	Trav T;
+	T.cur = kEmpty; T.lit = true; T.shadow = mk3(1.0f, 1.0f, 1.0f); T.cntNodes = 0; T.cntPrims = 0;
+	f3 lightPos = c;
 	if (live) {
 		s = (uint32_t)(j / ns);
 		const uint32_t smp = (uint32_t)(j % ns);
@@ -651,10 +860,11 @@ __global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, 
 			xDisplacement = displacement * cosf(angle);
 			yDisplacement = displacement * sinf(angle);
 		}
-		const f3 lightPos = ld3(L.position) + ld3(L.planeX) * xDisplacement + ld3(L.planeY) * yDisplacement;
-		Trav T;
+		lightPos = ld3(L.position) + ld3(L.planeX) * xDisplacement + ld3(L.planeY) * yDisplacement;
 		travInit<true>(S, T, sf.p, lightPos - sf.p);
-		while (T.cur != kEmpty) travRound<true, CSG, COUNT>(S, stack, T);
+	}
+	packetTraverse<true, CSG, COUNT>(S, wstack[threadIdx.x >> 6], T, live);
+	if (live) {
 		if (COUNT) { atomicAdd(&ctr->nodes_shadow, T.cntNodes); atomicAdd(&ctr->prims_shadow, T.cntPrims); }
 		if (T.lit) c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
 	}
@@ -739,7 +949,12 @@ void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, i
 void rtk_load_rays(hipStream_t st, const float* a, const float* b, uint32_t n, int bIsTarget, RtQueue rq, uint32_t pixBase) {
 	RT_LAUNCH(k_load_rays, n, st, a, b, n, bIsTarget, rq, pixBase);
 }
-void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
+void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
+	if (coherent) {
+		if (csg) { if (count) RT_LAUNCH_P((k_intersect_packet<true, true>), n, maxBlocks, st, S, rq, n, hq, ctr); else RT_LAUNCH_P((k_intersect_packet<true, false>), n, maxBlocks, st, S, rq, n, hq, ctr); }
+		else { if (count) RT_LAUNCH_P((k_intersect_packet<false, true>), n, maxBlocks, st, S, rq, n, hq, ctr); else RT_LAUNCH_P((k_intersect_packet<false, false>), n, maxBlocks, st, S, rq, n, hq, ctr); }
+		return;
+	}
 	if (csg) { if (count) RT_LAUNCH_P((k_intersect<true, true>), n, maxBlocks, st, S, rq, n, hq, ctr); else RT_LAUNCH_P((k_intersect<true, false>), n, maxBlocks, st, S, rq, n, hq, ctr); }
 	else { if (count) RT_LAUNCH_P((k_intersect<false, true>), n, maxBlocks, st, S, rq, n, hq, ctr); else RT_LAUNCH_P((k_intersect<false, false>), n, maxBlocks, st, S, rq, n, hq, ctr); }
 }
@@ -751,9 +966,15 @@ void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue 
 	if (csg) RT_LAUNCH((k_shade<true>), n, st, S, rq, hq, n, nq, sq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT);
 	else RT_LAUNCH((k_shade<false>), n, st, S, rq, hq, n, nq, sq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT);
 }
-void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
+void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                       RtAccum A, uint32_t aaSq, RtCounters* ctr) {
 	const unsigned long long items = (unsigned long long)nsurf * nLights;
+	if (coherent) {
+		const unsigned long long pitems = (unsigned long long)((nsurf + 63u) / 64u) * 64u * nLights;
+		if (csg) { if (count) RT_LAUNCH_P((k_shadow_point_packet<true, true>), pitems, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_P((k_shadow_point_packet<true, false>), pitems, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
+		else { if (count) RT_LAUNCH_P((k_shadow_point_packet<false, true>), pitems, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_P((k_shadow_point_packet<false, false>), pitems, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
+		return;
+	}
 	if (csg) { if (count) RT_LAUNCH_P((k_shadow_point<true, true>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_P((k_shadow_point<true, false>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
 	else { if (count) RT_LAUNCH_P((k_shadow_point<false, true>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_P((k_shadow_point<false, false>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
 }

@@ -126,7 +126,7 @@ struct Run {
 		bool shadowPending = false;
 		uint64_t nearRays = 0, shadowRays = 0, nLevels = 0;
 		for (int level = 0; level <= maxDepth && n > 0; level++) {
-			HIPCHK(hipMemsetAsync(sc->ctr, 0, 4 * sizeof(uint32_t), st));   // next_count, surf_count, head_nearest, head_shadow
+			HIPCHK(hipMemsetAsync(sc->ctr, 0, RT_COUNTER_RESET_BYTES, st));   // queue counts and work cursors
 			if (timeK) HIPCHK(hipEventRecord(sc->ev[2], st));
 			rtk_intersect(st, sc->dev, sc->hasCsg, count, coherent(level), sc->maxBlocks, sc->ray[cur], n, sc->hitq, sc->ctr);
 			if (timeK) HIPCHK(hipEventRecord(sc->ev[3], st));
@@ -404,7 +404,7 @@ int rt_intersect_batch(rt_scene* sc, const float* e, const float* d, size_t n, u
 	Run run{ sc, st, {}, 0, 0, flags, 1u };
 	for (size_t c0 = 0; c0 < n; c0 += sc->qcap) {
 		const uint32_t cnt = (uint32_t)std::min<size_t>(sc->qcap, n - c0);
-		HIPCHK(hipMemsetAsync(sc->ctr, 0, 4 * sizeof(uint32_t), st));
+		HIPCHK(hipMemsetAsync(sc->ctr, 0, RT_COUNTER_RESET_BYTES, st));
 		rtk_load_rays(st, de.as<float>() + 3 * c0, dd.as<float>() + 3 * c0, cnt, 0, sc->ray[0], 0);
 		rtk_intersect(st, sc->dev, sc->hasCsg, (flags & RT_FLAG_COUNTERS) != 0, false, sc->maxBlocks, sc->ray[0], cnt, sc->hitq, sc->ctr);
 		rtk_export_hits(st, sc->dev, sc->hitq, cnt, dhit.as<uint8_t>() + c0, did.as<int32_t>() + c0, dt.as<float>() + c0);

@@ -6,6 +6,9 @@
 #include "rt_device.h"
 
 #define RT_BLOCK 256          /* threads per workgroup = 4 wavefronts */
+#ifndef RT_PACKET_SCALAR_LOADS
+#define RT_PACKET_SCALAR_LOADS 0
+#endif
 #ifndef RT_REFILL_BELOW
 #define RT_REFILL_BELOW 48
 #endif
@@ -20,11 +23,12 @@ enum { HQ_PRIM, HQ_T, HQ_TAG, HQ_COMPS };                                       
 enum { SQ_PX, SQ_PY, SQ_PZ, SQ_NX, SQ_NY, SQ_NZ, SQ_VX, SQ_VY, SQ_VZ, SQ_KDR, SQ_KDG, SQ_KDB, SQ_KSR, SQ_KSG, SQ_KSB,
        SQ_SHIN, SQ_WR, SQ_WG, SQ_WB, SQ_PIX, SQ_PATH, SQ_COMPS };                                     // surface: what the light loop needs (p, N, V, kd, ks, shininess, weight)
 
+#define RT_COUNTER_RESET_BYTES (4 * 4)
 struct RtCounters {
 	uint32_t next_count;      // rays appended to the next level's queue
 	uint32_t surf_count;      // surface records appended
 	uint32_t head_nearest;    // work cursors of the persistent kernels
-	uint32_t head_shadow;     // ---- the four words above are reset at the start of every level ----
+	uint32_t head_shadow;     // ---- everything above is reset at the start of every level (RT_COUNTER_RESET_BYTES) ----
 	uint32_t overflow;        // an append found its queue full (the batch is re-run in halves)
 	uint32_t pad;
 	unsigned long long nodes_nearest, prims_nearest;   // RT_FLAG_COUNTERS: 64 B nodes read / primitive tests in k_intersect

@@ -274,9 +274,18 @@ __device__ __forceinline__ void travRound(const DevScene& S, int32_t (*stack)[kB
 // ---------------------------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+#if RT_PACKET_SCALAR_LOADS
 typedef __attribute__((address_space(4))) const v4f cfloat4;   // constant address space + wave-uniform address => s_load
 typedef __attribute__((address_space(4))) const v2f cfloat2;
 typedef __attribute__((address_space(4))) const uint32_t cuint32;
+#else
+// Same-address vector loads (one cache line per wave instruction, served by the CU's L1).  The scalar cache is a
+// few KB shared between CUs: a 4 MB tree walked by ~80 waves per scalar cache misses on almost every node and the
+// scalar miss path then costs ~14k cycles per step (measured), against ~1-2k for a broadcast vector load.
+typedef const v4f cfloat4;
+typedef const v2f cfloat2;
+typedef const uint32_t cuint32;
+#endif
 
 __device__ __forceinline__ NodeRegs sloadNode(const rt_bvh_node* nodes, int32_t node) {   // node must be wave-uniform
 	cfloat4* q = (cfloat4*)(uintptr_t)(nodes + node);
@@ -492,6 +501,16 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RtQueue rq, ui
 	if (COUNT) { atomicAdd(&ctr->nodes_nearest, cn); atomicAdd(&ctr->prims_nearest, cp); }
 }
 
+// Packet hand-out: one device-wide cursor, one atomic per 64 rays.  (Measured alternatives, both dropped: cutting the
+// range into eight per-XCD parts so that each L2 sees one band of the image was 1.8x SLOWER on the C2 frame, and
+// handing packets out in a scattered order to avoid neighbouring waves walking the same lines gained only 5 %.)
+__device__ __forceinline__ uint32_t fetchPacket(uint32_t* head, uint32_t nPackets) {
+	uint32_t k = 0;
+	if (__lane_id() == 0) k = atomicAdd(head, 1u);
+	k = __builtin_amdgcn_readfirstlane(k);
+	return k < nPackets ? k : kInactive;
+}
+
 // Nearest hit for coherent ray sets: one packet = 64 consecutive queue slots (an 8x8 pixel block of the tile order).
 template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_intersect_packet(DevScene S, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
@@ -500,10 +519,9 @@ __global__ __launch_bounds__(kBlock) void k_intersect_packet(DevScene S, RtQueue
 	uint32_t* ws = wstack[threadIdx.x >> 6];
 	unsigned long long cn = 0, cp = 0;
 	for (;;) {
-		uint32_t base = 0;
-		if (lane == 0) base = atomicAdd(&ctr->head_nearest, 64u);
-		base = __builtin_amdgcn_readfirstlane(base);
-		if (base >= n) break;
+		const uint32_t pk = fetchPacket(&ctr->head_nearest, (n + 63u) / 64u);
+		if (pk == kInactive) break;
+		const uint32_t base = pk * 64u;
 		const uint32_t idx = base + lane;
 		const bool alive = idx < n && qu(rq, RQ_PIX, idx < n ? idx : base) != kInactive;
 		Trav T;
@@ -800,10 +818,10 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point_packet(DevScene S, RtQu
 	const uint32_t totalPackets = packetsPerLight * nLights;
 	unsigned long long cn = 0, cp = 0;
 	for (;;) {
-		uint32_t pk = 0;
-		if (lane == 0) pk = atomicAdd(&ctr->head_shadow, 1u);
-		pk = __builtin_amdgcn_readfirstlane(pk);
-		if (pk >= totalPackets) break;
+		// light-minor numbering: the packets of one group of 64 surfaces towards every light are neighbours
+		const uint32_t q = fetchPacket(&ctr->head_shadow, totalPackets);
+		if (q == kInactive) break;
+		const uint32_t pk = (q % nLights) * packetsPerLight + q / nLights;
 		const rt_light L = S.lights[lightList[pk / packetsPerLight]];
 		const uint32_t s = (pk % packetsPerLight) * 64u + lane;
 		const bool alive = s < nsurf;

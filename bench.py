@@ -49,6 +49,7 @@ def main():
     import torch.distributed as dist
     import raytracer_amd as rt
     from raytracer_amd import scenes
+    from raytracer_amd import distributed as rd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -81,30 +82,19 @@ def main():
     frame = torch.zeros(H, W, 3, device=dev, dtype=torch.float32)
     ntiles = scene.tiles_count(W, H, rank, world)
     packed = torch.zeros(ntiles * 256 * 3, device=dev, dtype=torch.float32)
-    gather_list = None
-    if world > 1 and rank == 0:
-        gather_list = [torch.zeros(scene.tiles_count(W, H, r, world) * 256 * 3, device=dev, dtype=torch.float32) for r in range(world)]
     stream = torch.cuda.current_stream(dev).cuda_stream
+
+    sizes = [scene.tiles_count(W, H, r, world) * 256 * 3 for r in range(world)]
 
     def step(flags=0):
         st = scene.render_into(frame.data_ptr(), W, H, aa=(ax, ay), camera=cam, tile_rank=rank, tile_ranks=world, stream=stream, flags=flags)
         if world > 1:
-            # tiles -> rank 0 (RCCL gather over xGMI), then de-interleave into the full frame
+            # tiles -> rank 0 (RCCL gather over xGMI; point-to-point when the tile counts are ragged), then de-interleave
             scene.tiles_pack(frame.data_ptr(), packed.data_ptr(), W, H, rank, world, stream=stream)
-            sizes_equal = all(scene.tiles_count(W, H, r, world) == ntiles for r in range(world))
-            if sizes_equal:
-                dist.gather(packed, gather_list, dst=0)
-            else:   # ragged tile counts: point-to-point into rank 0
-                if rank == 0:
-                    reqs = [dist.irecv(gather_list[r], src=r) for r in range(1, world)]
-                    gather_list[0].copy_(packed)
-                    for q in reqs:
-                        q.wait()
-                else:
-                    dist.send(packed, dst=0)
+            bufs = rd.gather_packed(packed, sizes, rank, world)
             if rank == 0:
                 for r in range(1, world):
-                    scene.tiles_unpack(gather_list[r].data_ptr(), frame.data_ptr(), W, H, r, world, stream=stream)
+                    scene.tiles_unpack(bufs[r].data_ptr(), frame.data_ptr(), W, H, r, world, stream=stream)
         return st
 
     def barrier():

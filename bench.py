@@ -85,13 +85,14 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     sizes = [scene.tiles_count(W, H, r, world) * 256 * 3 for r in range(world)]
+    recv = [torch.zeros(n, device=dev, dtype=torch.float32) for n in sizes] if (world > 1 and rank == 0) else None
 
     def step(flags=0):
         st = scene.render_into(frame.data_ptr(), W, H, aa=(ax, ay), camera=cam, tile_rank=rank, tile_ranks=world, stream=stream, flags=flags)
         if world > 1:
             # tiles -> rank 0 (RCCL gather over xGMI; point-to-point when the tile counts are ragged), then de-interleave
             scene.tiles_pack(frame.data_ptr(), packed.data_ptr(), W, H, rank, world, stream=stream)
-            bufs = rd.gather_packed(packed, sizes, rank, world)
+            bufs = rd.gather_packed(packed, sizes, rank, world, bufs=recv)
             if rank == 0:
                 for r in range(1, world):
                     scene.tiles_unpack(bufs[r].data_ptr(), frame.data_ptr(), W, H, r, world, stream=stream)

@@ -54,14 +54,13 @@ def unpack_tiles(packed, frame, rank, ranks):
     frame.reshape(-1, 3)[pix[ok]] = torch.as_tensor(packed).reshape(-1, 3)[ok]
 
 
-def gather_packed(packed, sizes, rank, world, dst=0):
+def gather_packed(packed, sizes, rank, world, dst=0, bufs=None):
     """Gathers every rank's packed tile buffer (flat float tensor, sizes[r] elements for rank r) on `dst`.
     Equal sizes go through one gather collective; ragged sizes (tile count not divisible by the ranks) through
     point-to-point sends into the root.  Returns the list of buffers on dst, None elsewhere."""
     import torch
     import torch.distributed as dist
-    bufs = None
-    if rank == dst:
+    if rank == dst and bufs is None:
         bufs = [torch.empty(sizes[r], dtype=packed.dtype, device=packed.device) for r in range(world)]
     if world == 1:
         bufs[0].copy_(packed)

@@ -87,8 +87,9 @@ def main():
     sizes = [scene.tiles_count(W, H, r, world) * 256 * 3 for r in range(world)]
     recv = [torch.zeros(n, device=dev, dtype=torch.float32) for n in sizes] if (world > 1 and rank == 0) else None
 
-    def step(flags=0):
-        st = scene.render_into(frame.data_ptr(), W, H, aa=(ax, ay), camera=cam, tile_rank=rank, tile_ranks=world, stream=stream, flags=flags)
+    def step(flags=0, max_depth=rt.MAX_REFLECTIONS):
+        st = scene.render_into(frame.data_ptr(), W, H, aa=(ax, ay), camera=cam, tile_rank=rank, tile_ranks=world, stream=stream, flags=flags,
+                               max_depth=max_depth)
         if world > 1:
             # tiles -> rank 0 (RCCL gather over xGMI; point-to-point when the tile counts are ragged), then de-interleave
             scene.tiles_pack(frame.data_ptr(), packed.data_ptr(), W, H, rank, world, stream=stream)
@@ -122,28 +123,42 @@ def main():
         rays = int(rr.item())
 
     # ---- roofline of the dominant kernel: live hipEvent timing of the traversal launches + an untimed counting pass ----
-    timed = [step(flags=rt.RT_FLAG_TIME_KERNELS) for _ in range(3)][-1]
-    counted = step(flags=rt.RT_FLAG_COUNTERS)
+    # The two traversal kernels of level 0 (primary rays and their shadow rays: the packet kernels) carry the frame.
+    # They are isolated by rendering with max_depth 0 -- level 0 launches exactly the same two kernels on exactly the
+    # same rays whatever the depth limit -- so each hipEvent bracket below is ONE launch of ONE kernel.
+    timed_all = [step(flags=rt.RT_FLAG_TIME_KERNELS, max_depth=0) for _ in range(5)]
+    counted = step(flags=rt.RT_FLAG_COUNTERS, max_depth=0)
+    full = step(flags=rt.RT_FLAG_TIME_KERNELS)
     barrier()
     roofline = None
     if rank == 0:
-        near_ms, shad_ms = timed["nearest_ms"], timed["shadow_ms"]
-        nlaunch_near = max(1, timed["levels"])
+        near_ms = float(np.mean([t["nearest_ms"] for t in timed_all[1:]]))
+        shad_ms = float(np.mean([t["shadow_ms"] for t in timed_all[1:]]))
         n_sph = flat.info.n_spheres
         # algorithmic bytes: nodes read, primitive records tested, queue records read and written
         near_bytes = (counted["nodes_nearest"] * NODE_BYTES + counted["prims_nearest"] * TRI_BYTES +
                       counted["rays_nearest"] * (RAY_QUEUE_BYTES + HIT_QUEUE_BYTES))
         shad_bytes = (counted["nodes_shadow"] * NODE_BYTES + counted["prims_shadow"] * TRI_BYTES + counted["rays_shadow"] * SURF_BYTES)
         if shad_ms >= near_ms:
-            kname, ms, nbytes, launches = "k_shadow_point", shad_ms, shad_bytes, max(1, timed["levels"])
+            kname, ms, nbytes = "k_shadow_point_packet", shad_ms, shad_bytes
         else:
-            kname, ms, nbytes, launches = "k_intersect", near_ms, near_bytes, nlaunch_near
+            kname, ms, nbytes = "k_intersect_packet", near_ms, near_bytes
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        # HBM-side bytes per launch of that kernel from the PMC passes (tools/pmc_passes.sh -> profiles/r01_traffic.json:
+        # FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes); counters cannot be read from inside this process
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                traffic = json.load(f).get(kname, {}).get("traffic_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "launch_ms": round(ms / launches, 4), "launches_per_step": launches,
-                    "algorithmic_bytes_per_launch": int(nbytes / launches),
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "launch_ms": round(ms, 4), "launches_per_step": 1,
+                    "algorithmic_bytes_per_launch": int(nbytes),
                     "nearest_ms": round(near_ms, 4), "shadow_ms": round(shad_ms, 4),
+                    "all_levels_nearest_ms": round(full["nearest_ms"], 4), "all_levels_shadow_ms": round(full["shadow_ms"], 4),
+                    "levels": int(full["levels"]),
                     "nodes_per_ray_nearest": round(counted["nodes_nearest"] / max(1, counted["rays_nearest"]), 2),
                     "nodes_per_ray_shadow": round(counted["nodes_shadow"] / max(1, counted["rays_shadow"]), 2),
                     "prims_per_ray_nearest": round(counted["prims_nearest"] / max(1, counted["rays_nearest"]), 2),

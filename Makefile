@@ -17,7 +17,7 @@ HIP_SRCS  := $(CSRC)/rt_kernels.hip $(CSRC)/rt_capi_device.hip
 HOST_OBJS := $(patsubst $(CSRC)/host/%.cpp,$(OBJ)/host_%.o,$(HOST_SRCS))
 HIP_OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJ)/hip_%.o,$(HIP_SRCS))
 
-.PHONY: all lib oracle cli clean
+.PHONY: all lib oracle cli clean prof
 all: lib cli oracle
 lib: $(LIB)
 cli: raytracer_amd/bin/rt_render
@@ -36,6 +36,12 @@ $(LIB): $(HOST_OBJS) $(HIP_OBJS)
 raytracer_amd/bin/rt_render: $(CSRC)/host/render_cli.cpp $(LIB)
 	@mkdir -p $(dir $@)
 	$(CXX) $(CXXFLAGS) -o $@ $< -Lraytracer_amd/lib -lraytracer_amd -Wl,-rpath,'$$ORIGIN/../lib'
+# instrumented build (per-phase shader-clock sums in the packet kernels, printed when RT_PROF_PRINT is set); use through RT_LIB_PATH
+prof:
+	@mkdir -p $(OBJ)/prof
+	$(HIPCC) $(HIPFLAGS) -DRT_PROF=1 -c $(CSRC)/rt_kernels.hip -o $(OBJ)/prof/hip_rt_kernels.o
+	$(HIPCC) $(HIPFLAGS) -DRT_PROF=1 -c $(CSRC)/rt_capi_device.hip -o $(OBJ)/prof/hip_rt_capi_device.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o raytracer_amd/lib/libraytracer_amd_prof.so $(HOST_OBJS) $(OBJ)/prof/hip_rt_kernels.o $(OBJ)/prof/hip_rt_capi_device.o
 clean:
 	rm -rf $(OBJ) $(LIB) raytracer_amd/bin
 	$(MAKE) -C oracle clean

@@ -6,6 +6,7 @@
 #include "host/host_internal.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -89,6 +90,58 @@ int treeDepth(const rt_flat_scene* s) {
 			if (s->bvh_nodes[n].child[k] >= 0) st.push_back({ s->bvh_nodes[n].child[k], d + 1 });
 	}
 	return maxDepth;
+}
+
+// Leaf -> aux word of a treelet slot (rt_kernels.h): a run of 1..63 consecutive triangles is read straight from tris[].
+uint32_t leafRun(const rt_flat_scene* s, int32_t leafRef) {
+	int64_t at = ~leafRef;
+	uint32_t first = 0, count = 0;
+	for (;; at++) {
+		const uint32_t e = s->leaf_prims[at];
+		if (RT_PRIM_TYPE(e) != RT_PRIM_TRI) return RT_TREELET_NO_RUN;
+		const uint32_t ix = RT_PRIM_INDEX(e & ~RT_PRIM_LAST);
+		if (count == 0) first = ix;
+		else if (ix != first + count) return RT_TREELET_NO_RUN;
+		count++;
+		if (e & RT_PRIM_LAST) break;
+		if (count >= RT_TREELET_RUN_MAX) return RT_TREELET_NO_RUN;
+	}
+	if (first >= (1u << 26) - 1u) return RT_TREELET_NO_RUN;
+	return count << 26 | first;
+}
+
+// Cuts the binary tree into treelets (layout in rt_kernels.h).  Returns the number of treelet levels.
+int buildTreelets(const rt_flat_scene* s, std::vector<rt_bvh_node>& out) {
+	out.clear();
+	if (s->root_child < 0) return 0;
+	struct Root { int32_t node; int level; };
+	std::vector<Root> roots{ { s->root_child, 0 } };
+	int levels = 0;
+	std::vector<int32_t> member;
+	for (size_t t = 0; t < roots.size(); t++) {
+		out.resize((t + 1) * RT_TREELET_SLOTS, rt_bvh_node{});
+		levels = std::max(levels, roots[t].level + 1);
+		member.assign(1, roots[t].node);
+		for (size_t i = 0; i < member.size(); i++) {   // breadth-first: slot i's children take the next free slots
+			const rt_bvh_node& b = s->bvh_nodes[member[i]];
+			rt_bvh_node& o = out[t * RT_TREELET_SLOTS + i];
+			memcpy(o.box, b.box, sizeof o.box);
+			for (int k = 0; k < 2; k++) {
+				const int32_t c = b.child[k];
+				if (c < 0) { o.child[k] = c; o.count[k] = (int32_t)leafRun(s, c); }
+				else if (member.size() < RT_TREELET_NODES) {
+					o.child[k] = (int32_t)(t * RT_TREELET_SLOTS + member.size());
+					o.count[k] = 0;
+					member.push_back(c);
+				} else {
+					o.child[k] = (int32_t)(roots.size() * RT_TREELET_SLOTS);
+					o.count[k] = 0;
+					roots.push_back({ c, roots[t].level + 1 });
+				}
+			}
+		}
+	}
+	return levels;
 }
 
 // Where a call's rays come from and where first-level results go.
@@ -205,6 +258,18 @@ int finish(rt_scene* sc, hipStream_t st, Run& run, rt_stats* stats) {
 		run.stats.nodes_shadow = sc->ctrHost->nodes_shadow; run.stats.prims_shadow = sc->ctrHost->prims_shadow;
 		run.stats.max_walk = (float)sc->ctrHost->pad;   // longest nearest-hit walk of the call, in nodes (diagnostic)
 	}
+#if RT_PROF
+	if (getenv("RT_PROF_PRINT")) {
+		RtCounters c;
+		HIPCHK(hipMemcpy(&c, sc->ctr, sizeof c, hipMemcpyDeviceToHost));
+		static const char* names[8] = { "fetch", "load+init", "traverse", "stage", "leaves", "epilogue", "packets", "nodesteps" };
+		for (int k = 0; k < 2; k++) {
+			fprintf(stderr, "[prof %s]", k ? "shadow " : "nearest");
+			for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.3fM", names[i], (double)c.prof[8 * k + i] / 1e6);
+			fprintf(stderr, "\n");
+		}
+	}
+#endif
 	if (stats) *stats = run.stats;
 	return RT_OK;
 }
@@ -274,6 +339,16 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	if ((rc = sc->upload(s->texels, s->n_texel_bytes, &D.texels))) return fail(rc);
 	if ((rc = sc->upload(s->bvh_nodes, s->n_bvh_nodes, &D.nodes))) return fail(rc);
 	if ((rc = sc->upload(s->leaf_prims, s->n_leaf_prims, &D.leaf_prims))) return fail(rc);
+	{
+		std::vector<rt_bvh_node> treelets;
+		const int levels = buildTreelets(s, treelets);
+		if (levels > RT_TREELET_LEVELS || treelets.size() / RT_TREELET_SLOTS >= (1u << 27)) { rt::set_error("BVH too deep or too large for the treelet layout"); return fail(RT_ELIMIT); }
+		const rt_bvh_node* tl = nullptr;
+		if ((rc = sc->upload(treelets.data(), (int64_t)treelets.size(), &tl))) return fail(rc);
+		D.treelets = reinterpret_cast<const float4*>(tl);
+		D.treelet_root = s->root_child < 0 ? s->root_child : 0;
+		D.treelet_root_aux = (s->root_child < 0 && s->root_count > 0) ? leafRun(s, s->root_child) : RT_TREELET_NO_RUN;
+	}
 	D.n_planes = s->n_planes; D.n_lights = s->n_lights;
 	D.root_child = s->root_child; D.root_count = s->root_count;
 	memcpy(D.root_box, s->root_box, sizeof D.root_box);

@@ -142,6 +142,9 @@ struct DevScene {
 	const uint8_t* texels;
 	const rt_bvh_node* nodes;
 	const uint32_t* leaf_prims;
+	const float4* treelets;            // the same tree cut into 1 KB treelets of up to 15 nodes (rt_kernels.h), device-only
+	int32_t treelet_root;              // 0 (slot 0 of treelet 0) or, for a one-leaf tree, the leaf reference
+	uint32_t treelet_root_aux;
 	int32_t n_planes, n_lights;
 	int32_t root_child, root_count;
 	float root_box[6];

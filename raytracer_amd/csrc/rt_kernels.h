@@ -16,6 +16,21 @@
                                  a nearer-child-first walk of a binary tree needs at most its depth, and the
                                  reference's build stops at depth 16 (bvh.h:6); checked at upload */
 
+// Treelets (packet traversal): the BVH regrouped into records of 16 slots x 64 B = 1 KB.  A slot has the layout of
+// rt_bvh_node (two child boxes, two child references) with count[] replaced by aux[]:
+//   child >= 0   inner node, value = treelet * 16 + slot; a child in ANOTHER treelet always points at its slot 0
+//   child <  0   leaf, ~child = first entry in leaf_prims (as in rt_bvh_node)
+//   aux          for a leaf child whose primitives are 1..63 consecutive triangles: count << 26 | index of the first in
+//                tris[]; RT_TREELET_NO_RUN otherwise (the leaf is then read through leaf_prims)
+// A treelet is filled breadth-first from its root, so every exit lies at least RT_TREELET_MIN_DEPTH levels below the
+// root and a tree of depth <= RT_STACK_DEPTH has at most RT_TREELET_LEVELS treelets on any root-to-leaf path.
+#define RT_TREELET_SLOTS 16
+#define RT_TREELET_NODES 15
+#define RT_TREELET_MIN_DEPTH 4
+#define RT_TREELET_LEVELS 5
+#define RT_TREELET_NO_RUN 0xffffffffu
+#define RT_TREELET_RUN_MAX 63u
+
 // SoA queue: component c of slot i lives at f[c * cap + i]
 struct RtQueue { float* f; uint32_t cap; };
 enum { RQ_OX, RQ_OY, RQ_OZ, RQ_DX, RQ_DY, RQ_DZ, RQ_WR, RQ_WG, RQ_WB, RQ_PIX, RQ_PATH, RQ_COMPS };   // ray: origin, direction (unnormalised), RGB weight, pixel key, tree position
@@ -33,7 +48,11 @@ struct RtCounters {
 	uint32_t pad;
 	unsigned long long nodes_nearest, prims_nearest;   // RT_FLAG_COUNTERS: 64 B nodes read / primitive tests in k_intersect
 	unsigned long long nodes_shadow, prims_shadow;     // ... and in the shadow kernels
+	unsigned long long prof[16];                       // RT_PROF builds: per-phase shader-clock sums of the packet kernels
 };
+#ifndef RT_PROF
+#define RT_PROF 0
+#endif
 
 // 32.32 fixed-point accumulators: three planes of npix, plus a per-pixel "saw a NaN/inf" byte
 struct RtAccum { unsigned long long* rgb; uint8_t* nonfinite; uint32_t npix; };

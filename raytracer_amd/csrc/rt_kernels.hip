@@ -132,31 +132,34 @@ __device__ __forceinline__ NodeRegs loadNode(const rt_bvh_node* n) {   // one 64
 // ---------------------------------------------------------------------------------------------------------
 // Node test.  BoundingBox::intersect (objects.cpp:11-44) divides six times per box; on the device a correctly
 // rounded fp32 divide is ~11 VALU instructions, which made the two-box node test ~2/3 of all instructions.
-// Here the slabs are first evaluated with one multiply by the ray's precomputed 1/d (same compare/select
-// sequence, so zero / infinite / NaN cases behave exactly as with the divide).  Those t values are within 2 ulp of
-// the reference's, so every decision taken with a relative margin of 1e-6 is the reference's decision; only when
-// tnear/tfar/t_limit are closer than the margin is the exact divide-based test evaluated (rare, divergent).
+// Here the slabs are first evaluated with one multiply by the ray's precomputed 1/d.  Those t values are within 2 ulp
+// of the reference's, so every decision taken with a relative margin of 1e-6 is the reference's decision; only when
+// tnear / tfar / t_limit are closer than the margin is the exact divide-based test evaluated (rare, divergent:
+// 5 380 of 72 M tests on the C2 frame).  The hit condition of the reference, "tnear <= tfar, tfar >= 0, entry <=
+// limit" (entry = tnear, or 0 from inside the box), is tnear <= min(tfar, limit) and tfar >= 0; the sign of tfar
+// is that of the reference's quotient unless it underflows.  The (min, max) pairs of a box are neighbours in memory,
+// so the six subtractions and six multiplications are three packed instructions each.
+// A ray with a zero (or denormal) direction component has an infinite 1/d: 0 * inf then yields NaN where the
+// reference's d == 0 branch decides, so those rays (`special`) send every box with a NaN slab to the exact test.
 // Returns 0 = skip, 1 = visit, 2 = undecided.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void slabMul(float mn, float mx, float e, float inv, float& tnear, float& tfar) {
-	float t1 = (mn - e) * inv;
-	float t2 = (mx - e) * inv;
-	if (t1 > t2) { float s = t1; t1 = t2; t2 = s; }
-	if (t1 > tnear) tnear = t1;
-	if (t2 < tfar) tfar = t2;
-}
-__device__ __forceinline__ int boxClassify(const float* b, const f3& e, const f3& inv, float tlimit, float& tEntry) {
-	float tnear = -RT_MAX_T, tfar = RT_MAX_T;
-	slabMul(b[0], b[1], e.x, inv.x, tnear, tfar);
-	slabMul(b[2], b[3], e.y, inv.y, tnear, tfar);
-	slabMul(b[4], b[5], e.z, inv.z, tnear, tfar);
-	tEntry = tnear;
-	if (tnear > 3.0e38f || tfar < -3.0e38f) return 0;   // a zero direction component with the origin outside the slab: exact
-	const float m = 1e-6f * (fabsf(tnear) + fabsf(tfar)) + 1e-30f;
-	const float m2 = 1e-6f * (fabsf(tnear) + fabsf(tlimit));
-	if (tnear > tfar + m || tfar < -m || tnear > tlimit + m2) return 0;   // certainly missed, or certainly beyond the limit
-	if (tnear < tfar - m && tfar > m && tnear < tlimit - m2) return 1;    // certainly hit within the limit
-	return 2;
+typedef float v2f_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int boxClassify(const float* b, const f3& e, const f3& inv, bool special, float tlimit, float& tEntry) {
+	const v2f_ bx = { b[0], b[1] }, by = { b[2], b[3] }, bz = { b[4], b[5] };
+	const v2f_ tx = (bx - e.x) * inv.x, ty = (by - e.y) * inv.y, tz = (bz - e.z) * inv.z;
+	const float lo = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), -RT_MAX_T));
+	const float hi = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), RT_MAX_T));
+	tEntry = lo;
+	if (special) {
+		if (tx.x != tx.x || tx.y != tx.y || ty.x != ty.x || ty.y != ty.y || tz.x != tz.x || tz.y != tz.y) return 2;
+		if (lo > 3.0e38f || hi < -3.0e38f) return 0;   // origin outside a slab the ray runs parallel to: exact
+	}
+	const float u = fminf(hi, tlimit);
+	const float g = u - lo;
+	const float m = 1e-6f * (fabsf(lo) + fabsf(u)) + 1e-30f;
+	if (g > m && hi > 1e-30f) return 1;     // certainly hit within the limit
+	if (g < -m || hi < -1e-30f) return 0;   // certainly missed, or certainly beyond the limit
+	return 2;                               // too close to call (or not a number): the reference's own arithmetic decides
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -178,6 +181,7 @@ constexpr int32_t kEmpty = 0x7fffffff;
 
 struct Trav {
 	f3 e, d, inv;
+	bool special;   // 1/d is not finite on some axis (boxClassify)
 	int32_t cur;
 	int sp;
 	float tmin; uint32_t best, bestKey, bestTag;   // nearest
@@ -189,6 +193,7 @@ template <bool ANYHIT>
 __device__ __forceinline__ void travInit(const DevScene& S, Trav& T, f3 e, f3 d) {
 	T.e = e; T.d = d;
 	T.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	T.special = !(fabsf(T.inv.x) <= 3.0e38f && fabsf(T.inv.y) <= 3.0e38f && fabsf(T.inv.z) <= 3.0e38f);
 	T.sp = 0; T.cur = kEmpty;
 	T.cntNodes = 0; T.cntPrims = 0;
 	T.tmin = RT_MAX_T; T.best = RT_NO_HIT; T.bestKey = 0; T.bestTag = 0;   // bvh.cpp:73
@@ -239,8 +244,8 @@ __device__ __forceinline__ void travRound(const DevScene& S, int32_t (*stack)[kB
 		if (COUNT) T.cntNodes++;
 		const float tlimit = ANYHIT ? 1.0f : T.tmin;
 		float t0, t1;
-		int k0 = boxClassify(N.b0, T.e, T.inv, tlimit, t0);
-		int k1 = boxClassify(N.b1, T.e, T.inv, tlimit, t1);
+		int k0 = boxClassify(N.b0, T.e, T.inv, T.special, tlimit, t0);
+		int k1 = boxClassify(N.b1, T.e, T.inv, T.special, tlimit, t1);
 		if (k0 == 2 || k1 == 2) {   // too close to call with the multiply: the reference's own arithmetic decides
 			if (k0 == 2) { const float t = boxIntersect(N.b0, T.e, T.d, false); k0 = !(t < 0 || t > tlimit); }
 			if (k1 == 2) { const float t = boxIntersect(N.b1, T.e, T.d, false); k1 = !(t < 0 || t > tlimit); }
@@ -322,64 +327,126 @@ __device__ __forceinline__ float primHitUniform(const DevScene& S, uint32_t ref,
 	return 0.0f;
 }
 
-// `alive`: the lane holds a query.  T must come from travInit (T.cur == kEmpty: the lane's ray missed the root box).
-// wstack: this wave's kStack x 3 dwords of LDS.
+// Treelet staging.  A packet's walk is a chain of dependent fetches (child addresses are only known once the parent
+// has arrived) and each fetch from L2 costs a few thousand cycles, so the chain length, not bandwidth or arithmetic,
+// set the time of the first packet kernels.  The tree is therefore stored a second time as 1 KB treelets of up to 15
+// nodes, >= 4 levels each (rt_kernels.h): entering a treelet, the 64 lanes fetch it with ONE 16 B-per-lane load
+// and park it in the wave's LDS; the nodes inside are then read from LDS (all lanes the same address: a broadcast),
+// and only crossing into the next treelet touches memory again -- a 16-level tree is 4 dependent fetches deep instead
+// of 16.  One LDS buffer per treelet LEVEL: a depth-first walk only ever returns to ancestors of the treelet it is
+// in, and those are still resident in their level's buffer, so every treelet is fetched once per packet.
+#if RT_PROF
+#define PROF_DECL unsigned long long pf[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; unsigned long long pfT = __builtin_readcyclecounter();
+#define PROF_LAP(slot) do { const unsigned long long _n = __builtin_readcyclecounter(); pf[slot] += _n - pfT; pfT = _n; } while (0)
+#define PROF_ADD(slot, v) pf[slot] += (v)
+#define PROF_FLUSH(base) do { if (__lane_id() == 0) for (int _i = 0; _i < 8; _i++) atomicAdd(&ctr->prof[(base) + _i], pf[_i]); } while (0)
+#else
+#define PROF_DECL
+#define PROF_LAP(slot) do { } while (0)
+#define PROF_ADD(slot, v) do { } while (0)
+#define PROF_FLUSH(base) do { } while (0)
+#endif
+// prof slots: 0 fetch packet, 1 load rays + init, 2 traversal (minus 3 and 4), 3 treelet staging, 4 leaves, 5 epilogue, 6 packets, 7 node steps
+
+struct PacketLds {
+	float4 treelet[RT_TREELET_LEVELS][64];   // 5 KB per wave
+	uint32_t stack[kStack][4];               // node, lane mask lo/hi, level (inner) or aux (leaf)
+};
+
+// One triangle leaf entry / generic primitive for the lanes in `inSub`.
 template <bool ANYHIT, bool CSG, bool COUNT>
-__device__ __forceinline__ void packetTraverse(const DevScene& S, uint32_t* wstack, Trav& T, bool alive) {
+__device__ __forceinline__ void packetPrim(const DevScene& S, Trav& T, bool inSub, uint32_t ref, uint32_t key) {
+	if (inSub && (!ANYHIT || T.lit)) {
+		uint32_t tag = 0;
+		const float t = primHitUniform<CSG>(S, ref, T.e, T.d, tag);
+		if (COUNT) T.cntPrims++;
+		if (!ANYHIT) {   // bvh.cpp:109-118
+			if ((double)t > 1e-5 && (t < T.tmin || (t == T.tmin && key < T.bestKey))) { T.best = ref; T.bestTag = tag; T.tmin = t; T.bestKey = key; }
+		} else if (t < 1.0f && (double)(t * T.len) > 1e-5) {   // bvh.cpp:145-157
+			const float* kt = S.materials[primMaterial(S, ref)].transmissive;
+			if (!isZero3(kt)) T.shadow = T.shadow * ld3(kt);
+			else T.lit = false;
+		}
+	}
+}
+
+// `alive`: the lane holds a query.  T must come from travInit (T.cur == kEmpty: the lane's ray missed the root box).
+template <bool ANYHIT, bool CSG, bool COUNT>
+__device__ __forceinline__ void packetTraverse(const DevScene& S, PacketLds& L, Trav& T, bool alive, unsigned long long* pf = nullptr) {
 	const uint32_t lane = __lane_id();
+#if RT_PROF
+	unsigned long long pfT;
+#define PT_BEGIN() pfT = __builtin_readcyclecounter()
+#define PT_END(slot) pf[slot] += __builtin_readcyclecounter() - pfT
+#else
+#define PT_BEGIN() do { } while (0)
+#define PT_END(slot) do { } while (0)
+#endif
 	bool inSub = alive && T.cur != kEmpty;   // this lane's ray passed the box of the current node
 	if (__ballot(inSub) == 0) return;
-	int32_t node = S.root_child;
+	int32_t node = S.treelet_root;
+	uint32_t info = node < 0 ? S.treelet_root_aux : 0u;   // inner node: treelet level; leaf: aux
 	int sp = 0;
 	for (;;) {
 		node = __builtin_amdgcn_readfirstlane(node);
+		info = __builtin_amdgcn_readfirstlane(info);
 		bool popNext = true;
 		if (node >= 0) {
-			const NodeRegs N = sloadNode(S.nodes, node);
+			float4* buf = L.treelet[info];
+			if ((node & (RT_TREELET_SLOTS - 1)) == 0) {   // a treelet root: stage the treelet
+				PT_BEGIN();
+				buf[lane] = S.treelets[(size_t)node * 4 + lane];
+				__builtin_amdgcn_wave_barrier();
+				PT_END(3);
+			}
+			PROF_ADD(7, 1);
+			const float4* q = buf + (node & (RT_TREELET_SLOTS - 1)) * 4;
+			const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+			const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
+			const float b1[6] = { b.z, b.w, c.x, c.y, c.z, c.w };
+			const int32_t c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
 			int k0 = 0, k1 = 0;
 			float t0 = 0, t1 = 0;
 			if (inSub) {
 				if (COUNT) T.cntNodes++;
 				const float tlimit = ANYHIT ? 1.0f : T.tmin;
-				k0 = boxClassify(N.b0, T.e, T.inv, tlimit, t0);
-				k1 = boxClassify(N.b1, T.e, T.inv, tlimit, t1);
-				if (k0 == 2) { const float t = boxIntersect(N.b0, T.e, T.d, false); k0 = !(t < 0 || t > tlimit); }
-				if (k1 == 2) { const float t = boxIntersect(N.b1, T.e, T.d, false); k1 = !(t < 0 || t > tlimit); }
+				k0 = boxClassify(b0, T.e, T.inv, T.special, tlimit, t0);
+				k1 = boxClassify(b1, T.e, T.inv, T.special, tlimit, t1);
+				if (k0 == 2) { const float t = boxIntersect(b0, T.e, T.d, false); k0 = !(t < 0 || t > tlimit); }
+				if (k1 == 2) { const float t = boxIntersect(b1, T.e, T.d, false); k1 = !(t < 0 || t > tlimit); }
 			}
 			const unsigned long long m0 = __ballot(k0 != 0), m1 = __ballot(k1 != 0);
+			// what travels with a child: its treelet level (one more when it roots another treelet) or its leaf aux word
+			const uint32_t i0 = c0 < 0 ? __float_as_uint(d.z) : info + (((c0 ^ node) >> 4) != 0);
+			const uint32_t i1 = c1 < 0 ? __float_as_uint(d.w) : info + (((c1 ^ node) >> 4) != 0);
 			if (m0 != 0 && m1 != 0) {
 				// visit first the child most rays reach first (any order is correct; ties go to the reference's order by key)
 				const unsigned long long both = m0 & m1;
 				const bool swap = !ANYHIT && 2 * __popcll(__ballot(k0 && k1 && t1 < t0)) > __popcll(both);
 				const unsigned long long mFar = swap ? m0 : m1;
 				if (sp < kStack) {
-					wstack[3 * sp] = (uint32_t)(swap ? N.c0 : N.c1);
-					wstack[3 * sp + 1] = (uint32_t)mFar; wstack[3 * sp + 2] = (uint32_t)(mFar >> 32);
+					L.stack[sp][0] = (uint32_t)(swap ? c0 : c1);
+					L.stack[sp][1] = (uint32_t)mFar; L.stack[sp][2] = (uint32_t)(mFar >> 32);
+					L.stack[sp][3] = swap ? i0 : i1;
 					sp++;
 				}
-				node = swap ? N.c1 : N.c0;
+				node = swap ? c1 : c0; info = swap ? i1 : i0;
 				inSub = swap ? k1 != 0 : k0 != 0;
 				popNext = false;
-			} else if (m0 != 0) { node = N.c0; inSub = k0 != 0; popNext = false; }
-			else if (m1 != 0) { node = N.c1; inSub = k1 != 0; popNext = false; }
+			} else if (m0 != 0) { node = c0; info = i0; inSub = k0 != 0; popNext = false; }
+			else if (m1 != 0) { node = c1; info = i1; inSub = k1 != 0; popNext = false; }
+		} else if (info != RT_TREELET_NO_RUN) {   // leaf made of consecutive triangles: no leaf_prims indirection
+			PT_BEGIN();
+			const uint32_t first = info & ((1u << 26) - 1u), count = info >> 26;
+			const uint32_t key0 = (uint32_t)~node + 1u;
+			for (uint32_t k = 0; k < count; k++)
+				packetPrim<ANYHIT, CSG, COUNT>(S, T, inSub, RT_PRIM_REF(RT_PRIM_TRI, first + k), key0 + k);
+			PT_END(4);
 		} else {   // leaf: bvh.cpp:109-118 / 145-157 for the lanes whose ray passed this leaf's box
 			int32_t at = ~node;
 			for (;;) {
 				const uint32_t entry = *(cuint32*)(uintptr_t)(S.leaf_prims + at);
-				const uint32_t ref = entry & ~RT_PRIM_LAST;
-				if (inSub && (!ANYHIT || T.lit)) {
-					uint32_t tag = 0;
-					const float t = primHitUniform<CSG>(S, ref, T.e, T.d, tag);
-					if (COUNT) T.cntPrims++;
-					if (!ANYHIT) {
-						const uint32_t key = (uint32_t)at + 1u;
-						if ((double)t > 1e-5 && (t < T.tmin || (t == T.tmin && key < T.bestKey))) { T.best = ref; T.bestTag = tag; T.tmin = t; T.bestKey = key; }
-					} else if (t < 1.0f && (double)(t * T.len) > 1e-5) {
-						const float* kt = S.materials[primMaterial(S, ref)].transmissive;
-						if (!isZero3(kt)) T.shadow = T.shadow * ld3(kt);
-						else T.lit = false;
-					}
-				}
+				packetPrim<ANYHIT, CSG, COUNT>(S, T, inSub, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u);
 				if (entry & RT_PRIM_LAST) break;
 				at++;
 			}
@@ -388,8 +455,9 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, uint32_t* wsta
 			for (;;) {
 				if (sp == 0) return;
 				sp--;
-				const unsigned long long m = (unsigned long long)wstack[3 * sp + 1] | ((unsigned long long)wstack[3 * sp + 2] << 32);
-				node = (int32_t)wstack[3 * sp];
+				const unsigned long long m = (unsigned long long)L.stack[sp][1] | ((unsigned long long)L.stack[sp][2] << 32);
+				node = (int32_t)L.stack[sp][0];
+				info = L.stack[sp][3];
 				inSub = ((m >> lane) & 1ull) != 0 && (!ANYHIT || T.lit);
 				if (__ballot(inSub) != 0) break;   // nobody left who wants this subtree (occluded lanes)
 			}
@@ -401,6 +469,8 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, uint32_t* wsta
 // atomics per microsecond (MI355X_MICROARCH.md, row "dequeue"), and one atomic per lane refill made that cursor the
 // bottleneck of the whole launch.  Each wave therefore takes kWorkChunk consecutive indices per atomic into a
 // wave-local pool and refills its idle lanes from the pool.
+__device__ __forceinline__ uint32_t waveNumber() { return (blockIdx.x * kBlock + threadIdx.x) >> 6; }
+__device__ __forceinline__ uint32_t waveCount() { return gridDim.x * (kBlock / 64); }
 constexpr uint32_t kWorkChunk = 128;
 struct WorkPool { uint32_t next, end; bool drained; };
 
@@ -410,11 +480,11 @@ __device__ __forceinline__ uint32_t fetchWork(bool need, WorkPool& pool, uint32_
 	if (pool.next == pool.end && !pool.drained) {   // wave-uniform
 		uint32_t base = 0;
 		if (__lane_id() == 0) base = atomicAdd(head, kWorkChunk);
-		base = __builtin_amdgcn_readfirstlane(base);
-		if ((unsigned long long)base >= total) pool.drained = true;
+		const unsigned long long b = (unsigned long long)__builtin_amdgcn_readfirstlane(base) + (unsigned long long)waveCount() * kWorkChunk;
+		if (b >= total) pool.drained = true;
 		else {
-			pool.next = base;
-			pool.end = (uint32_t)((unsigned long long)base + kWorkChunk < total ? base + kWorkChunk : total);
+			pool.next = (uint32_t)b;
+			pool.end = (uint32_t)(b + kWorkChunk < total ? b + kWorkChunk : total);
 		}
 	}
 	const uint32_t avail = pool.end - pool.next;
@@ -423,6 +493,16 @@ __device__ __forceinline__ uint32_t fetchWork(bool need, WorkPool& pool, uint32_
 	const uint32_t cnt = (uint32_t)__popcll(mask);
 	pool.next += cnt < avail ? cnt : avail;
 	return mine;
+}
+// every wave starts on the chunk with its own number (no cursor stampede at launch, see fetchPacket)
+__device__ __forceinline__ WorkPool firstPool(unsigned long long total) {
+	const unsigned long long b = (unsigned long long)waveNumber() * kWorkChunk;
+	WorkPool p;
+	p.drained = false;
+	p.next = (uint32_t)(b < total ? b : total);
+	p.end = (uint32_t)(b + kWorkChunk < total ? b + kWorkChunk : total);
+	if (p.end < p.next) p.end = p.next;
+	return p;
 }
 __device__ __forceinline__ bool workLeft(const WorkPool& pool) { return !pool.drained || pool.next != pool.end; }
 constexpr int kRefillBelow = RT_REFILL_BELOW;   // fetch new queries once fewer than this many of the 64 lanes are still busy
@@ -471,7 +551,7 @@ template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
 	__shared__ int32_t stack[kStack][kBlock];
 	uint32_t idx = kInactive;
-	WorkPool pool = { 0u, 0u, false };
+	WorkPool pool = firstPool(n);
 	Trav T;
 	T.cur = kEmpty; T.sp = 0; T.cntNodes = 0; T.cntPrims = 0;
 	unsigned long long cn = 0, cp = 0;
@@ -501,40 +581,69 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RtQueue rq, ui
 	if (COUNT) { atomicAdd(&ctr->nodes_nearest, cn); atomicAdd(&ctr->prims_nearest, cp); }
 }
 
-// Packet hand-out: one device-wide cursor, one atomic per 64 rays.  (Measured alternatives, both dropped: cutting the
+// Packet hand-out.  Every wave starts on the packet with its own number and asks the device-wide cursor for the
+// ones after those, one atomic per 64 rays, issued as soon as the walk of the current packet is over.  (A cursor hit
+// by 8 000 waves in the same microsecond serves ~90 of them per microsecond: with the first packet handed out by the
+// cursor too, that stampede cost each wave ~45 us of a 650 us kernel, and because loads and returning atomics come
+// back in order it cannot be hidden behind other memory work.)  Measured alternatives, both dropped: cutting the
 // range into eight per-XCD parts so that each L2 sees one band of the image was 1.8x SLOWER on the C2 frame, and
-// handing packets out in a scattered order to avoid neighbouring waves walking the same lines gained only 5 %.)
+// handing packets out in a scattered order to avoid neighbouring waves walking the same lines gained only 5 %.
 __device__ __forceinline__ uint32_t fetchPacket(uint32_t* head, uint32_t nPackets) {
 	uint32_t k = 0;
 	if (__lane_id() == 0) k = atomicAdd(head, 1u);
-	k = __builtin_amdgcn_readfirstlane(k);
+	k = __builtin_amdgcn_readfirstlane(k) + waveCount();
 	return k < nPackets ? k : kInactive;
 }
 
 // Nearest hit for coherent ray sets: one packet = 64 consecutive queue slots (an 8x8 pixel block of the tile order).
 template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_intersect_packet(DevScene S, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
-	__shared__ uint32_t wstack[kBlock / 64][kStack * 3];
+	__shared__ PacketLds lds[kBlock / 64];
 	const uint32_t lane = __lane_id();
-	uint32_t* ws = wstack[threadIdx.x >> 6];
+	PacketLds& ws = lds[threadIdx.x >> 6];
+	const uint32_t nPackets = (n + 63u) / 64u;
 	unsigned long long cn = 0, cp = 0;
-	for (;;) {
-		const uint32_t pk = fetchPacket(&ctr->head_nearest, (n + 63u) / 64u);
-		if (pk == kInactive) break;
-		const uint32_t base = pk * 64u;
-		const uint32_t idx = base + lane;
-		const bool alive = idx < n && qu(rq, RQ_PIX, idx < n ? idx : base) != kInactive;
+	PROF_DECL
+	struct Rays { f3 e, d; bool alive; };
+	auto loadRays = [&](uint32_t pk) {
+		Rays r;
+		r.e = r.d = mk3(0, 0, 0); r.alive = false;
+		if (pk != kInactive) {
+			const uint32_t idx = pk * 64u + lane;
+			if (idx < n && qu(rq, RQ_PIX, idx) != kInactive) {
+				r.alive = true;
+				r.e = mk3(qf(rq, RQ_OX, idx), qf(rq, RQ_OY, idx), qf(rq, RQ_OZ, idx));
+				r.d = mk3(qf(rq, RQ_DX, idx), qf(rq, RQ_DY, idx), qf(rq, RQ_DZ, idx));
+			}
+		}
+		return r;
+	};
+	uint32_t pk = waveNumber() < nPackets ? waveNumber() : kInactive;
+	while (pk != kInactive) {
+		PROF_ADD(6, 1);
+		const Rays cur = loadRays(pk);
+		const uint32_t idx = pk * 64u + lane;
 		Trav T;
 		T.cur = kEmpty; T.best = RT_NO_HIT; T.tmin = 0; T.bestTag = 0; T.cntNodes = 0; T.cntPrims = 0;
-		if (alive) travInit<false>(S, T, mk3(qf(rq, RQ_OX, idx), qf(rq, RQ_OY, idx), qf(rq, RQ_OZ, idx)), mk3(qf(rq, RQ_DX, idx), qf(rq, RQ_DY, idx), qf(rq, RQ_DZ, idx)));
-		packetTraverse<false, CSG, COUNT>(S, ws, T, alive);
+		if (cur.alive) travInit<false>(S, T, cur.e, cur.d);
+#if RT_PROF
+		if (__ballot(T.tmin > 1e30f)) pf[5] += 1;   // keeps the ray loads ahead of the lap
+		PROF_LAP(1);
+		{ const unsigned long long s3 = pf[3], s4 = pf[4]; packetTraverse<false, CSG, COUNT>(S, ws, T, cur.alive, pf); PROF_LAP(2); pf[2] -= (pf[3] - s3) + (pf[4] - s4); }
+#else
+		packetTraverse<false, CSG, COUNT>(S, ws, T, cur.alive);
+#endif
+		pk = fetchPacket(&ctr->head_nearest, nPackets);
+		PROF_LAP(0);
 		if (idx < n) {
-			qsu(hq, HQ_PRIM, idx, alive ? T.best : RT_NO_HIT);
-			qsf(hq, HQ_T, idx, (alive && T.best != RT_NO_HIT) ? T.tmin : 0.0f);
+			qsu(hq, HQ_PRIM, idx, cur.alive ? T.best : RT_NO_HIT);
+			qsf(hq, HQ_T, idx, (cur.alive && T.best != RT_NO_HIT) ? T.tmin : 0.0f);
 			if (CSG) qsu(hq, HQ_TAG, idx, T.bestTag);
 		}
 		if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
+		PROF_LAP(5);
 	}
+	PROF_FLUSH(0);
 	if (COUNT) { atomicAdd(&ctr->nodes_nearest, cn); atomicAdd(&ctr->prims_nearest, cp); }
 }
 
@@ -767,7 +876,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq,
 	__shared__ int32_t stack[kStack][kBlock];
 	const unsigned long long total = (unsigned long long)nsurf * nLights;
 	uint32_t idx = kInactive;
-	WorkPool pool = { 0u, 0u, false };
+	WorkPool pool = firstPool(total);
 	Trav T;
 	T.cur = kEmpty; T.sp = 0; T.cntNodes = 0; T.cntPrims = 0; T.lit = true; T.shadow = mk3(1.0f, 1.0f, 1.0f);
 	unsigned long long cn = 0, cp = 0;
@@ -807,40 +916,65 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq,
 	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
 }
 
-// Packet form of k_shadow_point for coherent surface sets: 64 consecutive surfaces towards the same light.
+// Packet form of k_shadow_point for coherent surface sets: 64 consecutive surfaces towards the same light.  Only the
+// surface point is held during the walk; the rest of the surface record is read when the ray turned out lit.
 template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_shadow_point_packet(DevScene S, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                                                                 RtAccum A, uint32_t aaSq, RtCounters* ctr) {
-	__shared__ uint32_t wstack[kBlock / 64][kStack * 3];
+	__shared__ PacketLds lds[kBlock / 64];
 	const uint32_t lane = __lane_id();
-	uint32_t* ws = wstack[threadIdx.x >> 6];
+	PacketLds& ws = lds[threadIdx.x >> 6];
 	const uint32_t packetsPerLight = (nsurf + 63u) / 64u;
 	const uint32_t totalPackets = packetsPerLight * nLights;
 	unsigned long long cn = 0, cp = 0;
-	for (;;) {
-		// light-minor numbering: the packets of one group of 64 surfaces towards every light are neighbours
-		const uint32_t q = fetchPacket(&ctr->head_shadow, totalPackets);
-		if (q == kInactive) break;
-		const uint32_t pk = (q % nLights) * packetsPerLight + q / nLights;
-		const rt_light L = S.lights[lightList[pk / packetsPerLight]];
-		const uint32_t s = (pk % packetsPerLight) * 64u + lane;
+	PROF_DECL
+	// light-minor numbering: the packets of one group of 64 surfaces towards every light are neighbours
+	auto surfaceOf = [&](uint32_t q) { return (q / nLights) * 64u + lane; };
+	auto loadPoint = [&](uint32_t q) {
+		f3 p = mk3(0, 0, 0);
+		if (q != kInactive) {
+			const uint32_t s = surfaceOf(q);
+			if (s < nsurf) p = mk3(qf(sq, SQ_PX, s), qf(sq, SQ_PY, s), qf(sq, SQ_PZ, s));
+		}
+		return p;
+	};
+	uint32_t q = waveNumber() < totalPackets ? waveNumber() : kInactive;
+	while (q != kInactive) {
+		PROF_ADD(6, 1);
+		const f3 p = loadPoint(q);
+		const int lightIndex = lightList[q % nLights];
+		const uint32_t s = surfaceOf(q);
 		const bool alive = s < nsurf;
 		Trav T;
 		T.cur = kEmpty; T.lit = true; T.shadow = mk3(1.0f, 1.0f, 1.0f); T.cntNodes = 0; T.cntPrims = 0;
-		Surface sf;
-		f3 Ld = mk3(0, 0, 0), lightPos = Ld;
 		if (alive) {
-			sf = loadSurface(sq, s);
-			pointLightGeometry(L, sf.p, Ld, lightPos);
-			travInit<true>(S, T, sf.p, lightPos - sf.p);   // bvh.cpp:124
+			f3 Ld, lightPos;
+			pointLightGeometry(S.lights[lightIndex], p, Ld, lightPos);
+			travInit<true>(S, T, p, lightPos - p);   // bvh.cpp:124
 		}
+#if RT_PROF
+		if (__ballot(T.len > 1e30f)) pf[5] += 1;
+		PROF_LAP(1);
+		{ const unsigned long long s3 = pf[3], s4 = pf[4]; packetTraverse<true, CSG, COUNT>(S, ws, T, alive, pf); PROF_LAP(2); pf[2] -= (pf[3] - s3) + (pf[4] - s4); }
+#else
 		packetTraverse<true, CSG, COUNT>(S, ws, T, alive);
+#endif
+		q = fetchPacket(&ctr->head_shadow, totalPackets);
+		PROF_LAP(0);
 		if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
-		if (alive && T.lit && !(L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff))) {   // objects.cpp:451
-			const f3 c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
-			accumAdd(A, sf.pixKey / aaSq, sf.w * c);
+		if (alive && T.lit) {
+			const rt_light L = S.lights[lightIndex];
+			const Surface sf = loadSurface(sq, s);
+			f3 Ld, lightPos;
+			pointLightGeometry(L, sf.p, Ld, lightPos);
+			if (!(L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff))) {   // objects.cpp:451
+				const f3 c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
+				accumAdd(A, sf.pixKey / aaSq, sf.w * c);
+			}
 		}
+		PROF_LAP(5);
 	}
+	PROF_FLUSH(8);
 	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
 }
 
@@ -850,7 +984,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point_packet(DevScene S, RtQu
 template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t seed,
                                                         RtAccum A, uint32_t aaSq, RtCounters* ctr) {
-	__shared__ uint32_t wstack[kBlock / 64][kStack * 3];
+	__shared__ PacketLds lds[kBlock / 64];
 	const rt_light L = S.lights[lightIndex];
 	const uint32_t ns = (uint32_t)L.samples;
 	const unsigned long long j = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
@@ -881,7 +1015,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, 
 		lightPos = ld3(L.position) + ld3(L.planeX) * xDisplacement + ld3(L.planeY) * yDisplacement;
 		travInit<true>(S, T, sf.p, lightPos - sf.p);
 	}
-	packetTraverse<true, CSG, COUNT>(S, wstack[threadIdx.x >> 6], T, live);
+	packetTraverse<true, CSG, COUNT>(S, lds[threadIdx.x >> 6], T, live);
 	if (live) {
 		if (COUNT) { atomicAdd(&ctr->nodes_shadow, T.cntNodes); atomicAdd(&ctr->prims_shadow, T.cntPrims); }
 		if (T.lit) c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
@@ -959,7 +1093,17 @@ inline unsigned gridPersistent(unsigned long long n, int maxBlocks) { return (un
 // launch wrappers (host)
 // =========================================================================================================
 #define RT_LAUNCH(kernel, n, stream, ...) do { if ((n) > 0) hipLaunchKernelGGL(kernel, dim3(gridFor(n)), dim3(kBlock), 0, stream, __VA_ARGS__); } while (0)
-#define RT_LAUNCH_P(kernel, n, maxBlocks, stream, ...) do { if ((n) > 0) hipLaunchKernelGGL(kernel, dim3(gridPersistent(n, maxBlocks)), dim3(kBlock), 0, stream, __VA_ARGS__); } while (0)
+// Persistent kernels start every wave on a statically numbered piece of work, so the grid must not exceed what is
+// resident at once (a workgroup that only starts when another has finished would sit on its piece until the end).
+static int computeUnits() {
+	static int cus = 0;
+	if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+	return cus;
+}
+#define RT_LAUNCH_P(kernel, n, maxBlocks, stream, ...) do { if ((n) > 0) { \
+		static int _perCU = 0; \
+		if (!_perCU && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&_perCU, kernel, kBlock, 0) != hipSuccess || _perCU <= 0)) _perCU = 1; \
+		hipLaunchKernelGGL(kernel, dim3(gridPersistent(n, std::min(maxBlocks, _perCU * computeUnits()))), dim3(kBlock), 0, stream, __VA_ARGS__); } } while (0)
 
 void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, int aaY, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq) {
 	RT_LAUNCH(k_generate, count, st, cam, W, H, aaX, aaY, tileRank, tileRanks, r0, count, rq);

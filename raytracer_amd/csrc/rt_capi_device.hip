@@ -92,51 +92,90 @@ int treeDepth(const rt_flat_scene* s) {
 	return maxDepth;
 }
 
-// Leaf -> aux word of a treelet slot (rt_kernels.h): a run of 1..63 consecutive triangles is read straight from tris[].
-uint32_t leafRun(const rt_flat_scene* s, int32_t leafRef) {
-	int64_t at = ~leafRef;
-	uint32_t first = 0, count = 0;
-	for (;; at++) {
+// A leaf whose primitives are 1..63 consecutive triangles: (first index in tris[], count); count 0 otherwise.
+struct TriRun { uint32_t first = 0, count = 0; };
+TriRun leafRun(const rt_flat_scene* s, int32_t leafRef) {
+	TriRun r;
+	for (int64_t at = ~leafRef;; at++) {
 		const uint32_t e = s->leaf_prims[at];
-		if (RT_PRIM_TYPE(e) != RT_PRIM_TRI) return RT_TREELET_NO_RUN;
 		const uint32_t ix = RT_PRIM_INDEX(e & ~RT_PRIM_LAST);
-		if (count == 0) first = ix;
-		else if (ix != first + count) return RT_TREELET_NO_RUN;
-		count++;
+		if (RT_PRIM_TYPE(e) != RT_PRIM_TRI || (r.count > 0 && ix != r.first + r.count)) return TriRun{};
+		if (r.count == 0) r.first = ix;
+		r.count++;
 		if (e & RT_PRIM_LAST) break;
-		if (count >= RT_TREELET_RUN_MAX) return RT_TREELET_NO_RUN;
+		if (r.count >= RT_TREELET_RUN_MAX) return TriRun{};
 	}
-	if (first >= (1u << 26) - 1u) return RT_TREELET_NO_RUN;
-	return count << 26 | first;
+	if (r.first >= RT_TREELET_EMBED - RT_TREELET_RUN_MAX) return TriRun{};
+	return r;
 }
+uint32_t externalAux(const TriRun& r) { return r.count ? (r.count << 26 | r.first) : RT_TREELET_NO_RUN; }
 
 // Cuts the binary tree into treelets (layout in rt_kernels.h).  Returns the number of treelet levels.
-int buildTreelets(const rt_flat_scene* s, std::vector<rt_bvh_node>& out) {
+int buildTreelets(const rt_flat_scene* s, bool embed, std::vector<rt_bvh_node>& out, bool& externalRuns) {
 	out.clear();
+	externalRuns = false;
 	if (s->root_child < 0) return 0;
 	struct Root { int32_t node; int level; };
 	std::vector<Root> roots{ { s->root_child, 0 } };
 	int levels = 0;
-	std::vector<int32_t> member;
+	struct Member { int32_t node; bool embedLeaf[2]; };
+	std::vector<Member> member;
+	// triangles a node brings along if all its run leaves of at most RT_TREELET_EMBED_MAX triangles are embedded
+	auto runOf = [&](int32_t c) { TriRun r = leafRun(s, c); if (!embed || r.count > RT_TREELET_EMBED_MAX) r.count = 0; return r; };
 	for (size_t t = 0; t < roots.size(); t++) {
 		out.resize((t + 1) * RT_TREELET_SLOTS, rt_bvh_node{});
-		levels = std::max(levels, roots[t].level + 1);
-		member.assign(1, roots[t].node);
-		for (size_t i = 0; i < member.size(); i++) {   // breadth-first: slot i's children take the next free slots
-			const rt_bvh_node& b = s->bvh_nodes[member[i]];
+		const int level = roots[t].level;
+		levels = std::max(levels, level + 1);
+		member.clear();
+		uint32_t used = 0;
+		std::vector<std::pair<size_t, int>> exits;   // (member, child) that root further treelets, in creation order
+		auto join = [&](int32_t node, bool must) {
+			const rt_bvh_node& b = s->bvh_nodes[node];
+			uint32_t tris[2] = { 0, 0 };
+			for (int k = 0; k < 2; k++) if (b.child[k] < 0) tris[k] = runOf(b.child[k]).count;
+			if (!must && used + 1 + tris[0] + tris[1] > RT_TREELET_SLOTS) return false;
+			Member m{ node, { false, false } };
+			used += 1;
+			for (int k = 0; k < 2; k++)   // the root joins whatever it brings; its runs are embedded while they fit
+				if (tris[k] && used + tris[k] <= RT_TREELET_SLOTS) { m.embedLeaf[k] = true; used += tris[k]; }
+			member.push_back(m);
+			return true;
+		};
+		join(roots[t].node, true);
+		std::vector<int32_t> childSlot;   // per member, per child: slot of an in-treelet inner child, -1 otherwise
+		for (size_t i = 0; i < member.size(); i++) {
+			const rt_bvh_node& b = s->bvh_nodes[member[i].node];
+			for (int k = 0; k < 2; k++) {
+				int32_t slot = -1;
+				if (b.child[k] >= 0 && join(b.child[k], false)) slot = (int32_t)member.size() - 1;
+				childSlot.push_back(slot);
+			}
+		}
+		uint32_t triSlot = (uint32_t)member.size();
+		for (size_t i = 0; i < member.size(); i++) {
+			const rt_bvh_node& b = s->bvh_nodes[member[i].node];
 			rt_bvh_node& o = out[t * RT_TREELET_SLOTS + i];
 			memcpy(o.box, b.box, sizeof o.box);
 			for (int k = 0; k < 2; k++) {
 				const int32_t c = b.child[k];
-				if (c < 0) { o.child[k] = c; o.count[k] = (int32_t)leafRun(s, c); }
-				else if (member.size() < RT_TREELET_NODES) {
-					o.child[k] = (int32_t)(t * RT_TREELET_SLOTS + member.size());
+				if (c < 0) {
+					const TriRun r = leafRun(s, c);
+					o.child[k] = c;
+					if (member[i].embedLeaf[k]) {
+						o.count[k] = (int32_t)(r.count << 26 | RT_TREELET_EMBED | (uint32_t)level << 4 | triSlot);
+						for (uint32_t j = 0; j < r.count; j++, triSlot++) {
+							rt_tri tri = s->tris[r.first + j];
+							tri.mesh = (int32_t)(r.first + j);
+							memcpy(&out[t * RT_TREELET_SLOTS + triSlot], &tri, sizeof tri);
+						}
+					} else { o.count[k] = (int32_t)externalAux(r); externalRuns |= r.count != 0; }
+				} else if (childSlot[2 * i + k] >= 0) {
+					o.child[k] = (int32_t)(t * RT_TREELET_SLOTS + childSlot[2 * i + k]);
 					o.count[k] = 0;
-					member.push_back(c);
 				} else {
 					o.child[k] = (int32_t)(roots.size() * RT_TREELET_SLOTS);
 					o.count[k] = 0;
-					roots.push_back({ c, roots[t].level + 1 });
+					roots.push_back({ c, level + 1 });
 				}
 			}
 		}
@@ -259,15 +298,10 @@ int finish(rt_scene* sc, hipStream_t st, Run& run, rt_stats* stats) {
 		run.stats.max_walk = (float)sc->ctrHost->pad;   // longest nearest-hit walk of the call, in nodes (diagnostic)
 	}
 #if RT_PROF
-	if (getenv("RT_PROF_PRINT")) {
-		RtCounters c;
-		HIPCHK(hipMemcpy(&c, sc->ctr, sizeof c, hipMemcpyDeviceToHost));
-		static const char* names[8] = { "fetch", "load+init", "traverse", "stage", "leaves", "epilogue", "packets", "nodesteps" };
-		for (int k = 0; k < 2; k++) {
-			fprintf(stderr, "[prof %s]", k ? "shadow " : "nearest");
-			for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.3fM", names[i], (double)c.prof[8 * k + i] / 1e6);
-			fprintf(stderr, "\n");
-		}
+	if (const char* path = getenv("RT_TRACE_FILE")) {   // raw dump of RtCounters::trace (tools/trace_summary.py)
+		std::vector<RtCounters> c(1);
+		HIPCHK(hipMemcpy(c.data(), sc->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost));
+		if (FILE* f = fopen(path, "wb")) { fwrite(c[0].trace, sizeof c[0].trace, 1, f); fclose(f); }
 	}
 #endif
 	if (stats) *stats = run.stats;
@@ -340,14 +374,20 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	if ((rc = sc->upload(s->bvh_nodes, s->n_bvh_nodes, &D.nodes))) return fail(rc);
 	if ((rc = sc->upload(s->leaf_prims, s->n_leaf_prims, &D.leaf_prims))) return fail(rc);
 	{
+		static_assert(sizeof(rt_tri) == sizeof(rt_bvh_node) && sizeof(rt_bvh_node) == 64, "treelet slots are 64 B");
 		std::vector<rt_bvh_node> treelets;
-		const int levels = buildTreelets(s, treelets);
-		if (levels > RT_TREELET_LEVELS || treelets.size() / RT_TREELET_SLOTS >= (1u << 27)) { rt::set_error("BVH too deep or too large for the treelet layout"); return fail(RT_ELIMIT); }
+		bool externalRuns = false;
+		int levels = buildTreelets(s, getenv("RT_NO_EMBED") == nullptr, treelets, externalRuns);
+		if (levels > RT_TREELET_MAX_LEVELS) levels = buildTreelets(s, false, treelets, externalRuns);
+		if (levels > RT_TREELET_MAX_LEVELS || treelets.size() / RT_TREELET_SLOTS >= (1u << 27)) { rt::set_error("BVH too deep or too large for the treelet layout"); return fail(RT_ELIMIT); }
+		D.treelet_levels = levels;
+		D.treelet_staging = externalRuns ? 1 : 0;
 		const rt_bvh_node* tl = nullptr;
 		if ((rc = sc->upload(treelets.data(), (int64_t)treelets.size(), &tl))) return fail(rc);
 		D.treelets = reinterpret_cast<const float4*>(tl);
 		D.treelet_root = s->root_child < 0 ? s->root_child : 0;
-		D.treelet_root_aux = (s->root_child < 0 && s->root_count > 0) ? leafRun(s, s->root_child) : RT_TREELET_NO_RUN;
+		D.treelet_root_aux = (s->root_child < 0 && s->root_count > 0) ? externalAux(leafRun(s, s->root_child)) : RT_TREELET_NO_RUN;
+		if (D.treelet_root_aux != RT_TREELET_NO_RUN) D.treelet_staging = 1;
 	}
 	D.n_planes = s->n_planes; D.n_lights = s->n_lights;
 	D.root_child = s->root_child; D.root_count = s->root_count;

@@ -145,6 +145,8 @@ struct DevScene {
 	const float4* treelets;            // the same tree cut into 1 KB treelets of up to 15 nodes (rt_kernels.h), device-only
 	int32_t treelet_root;              // 0 (slot 0 of treelet 0) or, for a one-leaf tree, the leaf reference
 	uint32_t treelet_root_aux;
+	int32_t treelet_levels;            // treelets on the longest root-to-leaf path (sizes the packet kernels' LDS)
+	int32_t treelet_staging;           // some leaf is an external run (needs the staging buffer)
 	int32_t n_planes, n_lights;
 	int32_t root_child, root_count;
 	float root_box[6];

@@ -16,20 +16,30 @@
                                  a nearer-child-first walk of a binary tree needs at most its depth, and the
                                  reference's build stops at depth 16 (bvh.h:6); checked at upload */
 
-// Treelets (packet traversal): the BVH regrouped into records of 16 slots x 64 B = 1 KB.  A slot has the layout of
-// rt_bvh_node (two child boxes, two child references) with count[] replaced by aux[]:
+// Treelets (packet traversal): the BVH regrouped into records of 16 slots x 64 B = 1 KB.  A NODE slot has the layout
+// of rt_bvh_node (two child boxes, two child references) with count[] replaced by aux[]:
 //   child >= 0   inner node, value = treelet * 16 + slot; a child in ANOTHER treelet always points at its slot 0
 //   child <  0   leaf, ~child = first entry in leaf_prims (as in rt_bvh_node)
-//   aux          for a leaf child whose primitives are 1..63 consecutive triangles: count << 26 | index of the first in
-//                tris[]; RT_TREELET_NO_RUN otherwise (the leaf is then read through leaf_prims)
-// A treelet is filled breadth-first from its root, so every exit lies at least RT_TREELET_MIN_DEPTH levels below the
-// root and a tree of depth <= RT_STACK_DEPTH has at most RT_TREELET_LEVELS treelets on any root-to-leaf path.
+//   aux          for a leaf child whose primitives are 1..63 consecutive triangles (a "run"):
+//                  embedded run   count << 26 | RT_TREELET_EMBED | level << 4 | slot : its triangles sit in TRIANGLE
+//                                 slots slot .. slot+count-1 of this same treelet (`level` = the treelet's level)
+//                  external run   count << 26 | index of the first triangle in tris[] (< 2^25)
+//                RT_TREELET_NO_RUN otherwise (the leaf is then read through leaf_prims)
+// A TRIANGLE slot is a copy of the rt_tri record with `mesh` replaced by the triangle's index in tris[].
+// Node slots come first; a treelet is filled breadth-first from its root, a node joining only if its own embeddable
+// leaves fit as well, so a whole bottom subtree (nodes + triangles) arrives with one fetch.
 #define RT_TREELET_SLOTS 16
-#define RT_TREELET_NODES 15
-#define RT_TREELET_MIN_DEPTH 4
-#define RT_TREELET_LEVELS 5
+#define RT_TREELET_MAX_LEVELS 12          /* deeper cuts are rebuilt without embedding, which needs at most 5 */
 #define RT_TREELET_NO_RUN 0xffffffffu
+#define RT_TREELET_EMBED (1u << 25)
 #define RT_TREELET_RUN_MAX 63u
+#define RT_TREELET_EMBED_MAX 8u           /* longest run that is embedded */
+#define RT_PACKET_STACK_BYTES (RT_STACK_DEPTH * 16)
+// LDS of a packet kernel's workgroup: the root treelet once (every packet starts there; fetched when the workgroup
+// starts), then per wave one 1 KB buffer per deeper treelet level, one more when the scene has external runs to stage,
+// and the stack
+#define RT_PACKET_WAVE_LDS_BYTES(levels, staging) ((((levels) > 1 ? (levels) - 1 : 0) + ((staging) ? 1 : 0)) * 1024 + RT_PACKET_STACK_BYTES)
+#define RT_PACKET_LDS_BYTES(levels, staging) (1024 + (RT_BLOCK / 64) * RT_PACKET_WAVE_LDS_BYTES(levels, staging))
 
 // SoA queue: component c of slot i lives at f[c * cap + i]
 struct RtQueue { float* f; uint32_t cap; };
@@ -38,6 +48,10 @@ enum { HQ_PRIM, HQ_T, HQ_TAG, HQ_COMPS };                                       
 enum { SQ_PX, SQ_PY, SQ_PZ, SQ_NX, SQ_NY, SQ_NZ, SQ_VX, SQ_VY, SQ_VZ, SQ_KDR, SQ_KDG, SQ_KDB, SQ_KSR, SQ_KSG, SQ_KSB,
        SQ_SHIN, SQ_WR, SQ_WG, SQ_WB, SQ_PIX, SQ_PATH, SQ_COMPS };                                     // surface: what the light loop needs (p, N, V, kd, ks, shininess, weight)
 
+#ifndef RT_PROF
+#define RT_PROF 0
+#endif
+#define RT_TRACE_LEN 2048
 #define RT_COUNTER_RESET_BYTES (4 * 4)
 struct RtCounters {
 	uint32_t next_count;      // rays appended to the next level's queue
@@ -48,11 +62,10 @@ struct RtCounters {
 	uint32_t pad;
 	unsigned long long nodes_nearest, prims_nearest;   // RT_FLAG_COUNTERS: 64 B nodes read / primitive tests in k_intersect
 	unsigned long long nodes_shadow, prims_shadow;     // ... and in the shadow kernels
-	unsigned long long prof[16];                       // RT_PROF builds: per-phase shader-clock sums of the packet kernels
-};
-#ifndef RT_PROF
-#define RT_PROF 0
+#if RT_PROF
+	unsigned long long trace[2][4][RT_TRACE_LEN];      // RT_PROF builds: step traces of four waves of the two packet kernels
 #endif
+};
 
 // 32.32 fixed-point accumulators: three planes of npix, plus a per-pixel "saw a NaN/inf" byte
 struct RtAccum { unsigned long long* rgb; uint8_t* nonfinite; uint32_t npix; };

@@ -20,6 +20,8 @@
 #include "rt_kernels.h"
 #include "rt_device.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 using namespace rtd;
 
@@ -335,25 +337,56 @@ __device__ __forceinline__ float primHitUniform(const DevScene& S, uint32_t ref,
 // and only crossing into the next treelet touches memory again -- a 16-level tree is 4 dependent fetches deep instead
 // of 16.  One LDS buffer per treelet LEVEL: a depth-first walk only ever returns to ancestors of the treelet it is
 // in, and those are still resident in their level's buffer, so every treelet is fetched once per packet.
+__device__ __forceinline__ uint32_t waveNumber() { return (blockIdx.x * kBlock + threadIdx.x) >> 6; }
+__device__ __forceinline__ uint32_t waveCount() { return gridDim.x * (kBlock / 64); }
+
+// RT_PROF builds: four waves of each packet kernel record (tag, value, shader clock) at every step of their walk
+// into RtCounters::trace; tools/trace_summary.py turns that into per-phase cycle counts.  Tags: 1 packet start,
+// 2 rays loaded + init done, 3 node step start (value = slot), 4 treelet staged, 5 node read + classified,
+// 6 step end, 7 leaf start (value = count), 8 leaf end, 9 walk done, 10 next packet fetched, 11 results stored
 #if RT_PROF
-#define PROF_DECL unsigned long long pf[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; unsigned long long pfT = __builtin_readcyclecounter();
-#define PROF_LAP(slot) do { const unsigned long long _n = __builtin_readcyclecounter(); pf[slot] += _n - pfT; pfT = _n; } while (0)
-#define PROF_ADD(slot, v) pf[slot] += (v)
-#define PROF_FLUSH(base) do { if (__lane_id() == 0) for (int _i = 0; _i < 8; _i++) atomicAdd(&ctr->prof[(base) + _i], pf[_i]); } while (0)
+struct Tracer { unsigned long long* buf; uint32_t n; bool on; };
+__device__ __forceinline__ Tracer tracerFor(RtCounters* ctr, int kernel) {
+	Tracer tr;
+	const uint32_t w = waveNumber();
+	const int slot = w == 100u ? 0 : w == 1000u ? 1 : w == 2000u ? 2 : w == 3000u ? 3 : -1;
+	tr.on = slot >= 0; tr.n = 0; tr.buf = ctr->trace[kernel][slot < 0 ? 0 : slot];
+	return tr;
+}
+#define TR_DECL(kernel) Tracer tr = tracerFor(ctr, kernel); Tracer* trp = &tr;
+#define TR(tag, val) do { if (trp->on) { const unsigned long long _t = __builtin_readcyclecounter(); \
+	if (__lane_id() == 0 && trp->n < RT_TRACE_LEN) trp->buf[trp->n] = ((unsigned long long)(tag) << 56) | ((unsigned long long)((val) & 0xffffu) << 40) | (_t & 0xffffffffffull); trp->n++; } } while (0)
+#define TR_ARG , trp
 #else
-#define PROF_DECL
-#define PROF_LAP(slot) do { } while (0)
-#define PROF_ADD(slot, v) do { } while (0)
-#define PROF_FLUSH(base) do { } while (0)
+struct Tracer;
+#define TR_DECL(kernel)
+#define TR(tag, val) do { } while (0)
+#define TR_ARG
 #endif
-// prof slots: 0 fetch packet, 1 load rays + init, 2 traversal (minus 3 and 4), 3 treelet staging, 4 leaves, 5 epilogue, 6 packets, 7 node steps
 
 struct PacketLds {
-	float4 treelet[RT_TREELET_LEVELS][64];   // 5 KB per wave
-	uint32_t stack[kStack][4];               // node, lane mask lo/hi, level (inner) or aux (leaf)
+	float4* root;               // [64] the root treelet, shared by the workgroup's waves
+	float4* treelet;            // [levels - 1 (+ 1)][64]: this wave's buffer per deeper treelet level, then the staging buffer
+	uint32_t (*stack)[4];       // [kStack]: node, lane mask lo/hi, level (inner) or aux (leaf)
+	uint32_t staging;           // index of the staging buffer in treelet[]
+	__device__ __forceinline__ float4* level(uint32_t l) const { return l == 0 ? root : treelet + (l - 1u) * 64u; }
 };
+extern __shared__ float4 packetLdsRaw[];
+// Carves up the workgroup's dynamic LDS (RT_PACKET_LDS_BYTES) and fetches the root treelet.  Ends with a barrier:
+// call it once, at the top of the kernel, from every thread.
+__device__ __forceinline__ PacketLds packetLdsInit(const DevScene& S) {
+	PacketLds L;
+	const uint32_t perWave = RT_PACKET_WAVE_LDS_BYTES(S.treelet_levels, S.treelet_staging) / 16;
+	L.root = packetLdsRaw;
+	L.treelet = packetLdsRaw + 64 + (threadIdx.x >> 6) * perWave;
+	L.staging = S.treelet_levels > 1 ? (uint32_t)S.treelet_levels - 1u : 0u;
+	L.stack = reinterpret_cast<uint32_t (*)[4]>(L.treelet + (L.staging + (S.treelet_staging ? 1u : 0u)) * 64u);
+	if (threadIdx.x < 64 && S.treelet_root >= 0) L.root[threadIdx.x] = S.treelets[threadIdx.x];
+	__syncthreads();
+	return L;
+}
 
-// One triangle leaf entry / generic primitive for the lanes in `inSub`.
+// One generic primitive (wave-uniform reference, record fetched from memory) for the lanes in `inSub`.
 template <bool ANYHIT, bool CSG, bool COUNT>
 __device__ __forceinline__ void packetPrim(const DevScene& S, Trav& T, bool inSub, uint32_t ref, uint32_t key) {
 	if (inSub && (!ANYHIT || T.lit)) {
@@ -370,18 +403,26 @@ __device__ __forceinline__ void packetPrim(const DevScene& S, Trav& T, bool inSu
 	}
 }
 
+// bvh.cpp:109-118 / 145-157 for a triangle whose record is already in registers (same in every lane)
+template <bool ANYHIT, bool COUNT>
+__device__ __forceinline__ void packetTri(const DevScene& S, Trav& T, bool inSub, float4 a, float4 b, float4 c, uint32_t index, int mat, uint32_t key) {
+	if (inSub && (!ANYHIT || T.lit)) {
+		const float t = triHit(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), T.e, T.d, false);
+		if (COUNT) T.cntPrims++;
+		if (!ANYHIT) {
+			if ((double)t > 1e-5 && (t < T.tmin || (t == T.tmin && key < T.bestKey))) { T.best = RT_PRIM_REF(RT_PRIM_TRI, index); T.bestTag = 0; T.tmin = t; T.bestKey = key; }
+		} else if (t < 1.0f && (double)(t * T.len) > 1e-5) {
+			const float* kt = S.materials[mat].transmissive;
+			if (!isZero3(kt)) T.shadow = T.shadow * ld3(kt);
+			else T.lit = false;
+		}
+	}
+}
+
 // `alive`: the lane holds a query.  T must come from travInit (T.cur == kEmpty: the lane's ray missed the root box).
 template <bool ANYHIT, bool CSG, bool COUNT>
-__device__ __forceinline__ void packetTraverse(const DevScene& S, PacketLds& L, Trav& T, bool alive, unsigned long long* pf = nullptr) {
+__device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLds& L, Trav& T, bool alive, Tracer* trp = nullptr) {
 	const uint32_t lane = __lane_id();
-#if RT_PROF
-	unsigned long long pfT;
-#define PT_BEGIN() pfT = __builtin_readcyclecounter()
-#define PT_END(slot) pf[slot] += __builtin_readcyclecounter() - pfT
-#else
-#define PT_BEGIN() do { } while (0)
-#define PT_END(slot) do { } while (0)
-#endif
 	bool inSub = alive && T.cur != kEmpty;   // this lane's ray passed the box of the current node
 	if (__ballot(inSub) == 0) return;
 	int32_t node = S.treelet_root;
@@ -392,14 +433,13 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, PacketLds& L, 
 		info = __builtin_amdgcn_readfirstlane(info);
 		bool popNext = true;
 		if (node >= 0) {
-			float4* buf = L.treelet[info];
-			if ((node & (RT_TREELET_SLOTS - 1)) == 0) {   // a treelet root: stage the treelet
-				PT_BEGIN();
+			TR(3, node & 15);
+			float4* buf = L.level(info);
+			if ((node & (RT_TREELET_SLOTS - 1)) == 0 && node != 0) {   // the root of a deeper treelet: stage it
 				buf[lane] = S.treelets[(size_t)node * 4 + lane];
 				__builtin_amdgcn_wave_barrier();
-				PT_END(3);
+				TR(4, node >> 4);
 			}
-			PROF_ADD(7, 1);
 			const float4* q = buf + (node & (RT_TREELET_SLOTS - 1)) * 4;
 			const float4 a = q[0], b = q[1], c = q[2], d = q[3];
 			const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
@@ -416,6 +456,7 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, PacketLds& L, 
 				if (k1 == 2) { const float t = boxIntersect(b1, T.e, T.d, false); k1 = !(t < 0 || t > tlimit); }
 			}
 			const unsigned long long m0 = __ballot(k0 != 0), m1 = __ballot(k1 != 0);
+			TR(5, __popcll(m0 | m1));
 			// what travels with a child: its treelet level (one more when it roots another treelet) or its leaf aux word
 			const uint32_t i0 = c0 < 0 ? __float_as_uint(d.z) : info + (((c0 ^ node) >> 4) != 0);
 			const uint32_t i1 = c1 < 0 ? __float_as_uint(d.w) : info + (((c1 ^ node) >> 4) != 0);
@@ -435,13 +476,32 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, PacketLds& L, 
 				popNext = false;
 			} else if (m0 != 0) { node = c0; info = i0; inSub = k0 != 0; popNext = false; }
 			else if (m1 != 0) { node = c1; info = i1; inSub = k1 != 0; popNext = false; }
+			TR(6, sp);
 		} else if (info != RT_TREELET_NO_RUN) {   // leaf made of consecutive triangles: no leaf_prims indirection
-			PT_BEGIN();
-			const uint32_t first = info & ((1u << 26) - 1u), count = info >> 26;
+			const uint32_t count = info >> 26;
+			TR(7, count);
 			const uint32_t key0 = (uint32_t)~node + 1u;
-			for (uint32_t k = 0; k < count; k++)
-				packetPrim<ANYHIT, CSG, COUNT>(S, T, inSub, RT_PRIM_REF(RT_PRIM_TRI, first + k), key0 + k);
-			PT_END(4);
+			if (info & RT_TREELET_EMBED) {   // ... which arrived with the treelet
+				const float4* q = L.level((info >> 4) & 15u) + (info & 15u) * 4u;
+				for (uint32_t k = 0; k < count; k++, q += 4) {
+					const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+					packetTri<ANYHIT, COUNT>(S, T, inSub, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), key0 + k);
+				}
+			} else {   // ... fetched 16 at a time (64 lanes x 16 B) into the staging buffer
+				const uint32_t first = info & (RT_TREELET_EMBED - 1u);
+				float4* buf = L.treelet + L.staging * 64u;
+				for (uint32_t k0 = 0; k0 < count; k0 += 16u) {
+					const uint32_t nb = count - k0 < 16u ? count - k0 : 16u;
+					if (lane < nb * 4u) buf[lane] = reinterpret_cast<const float4*>(S.tris + first + k0)[lane];
+					__builtin_amdgcn_wave_barrier();
+					for (uint32_t k = 0; k < nb; k++) {
+						const float4 a = buf[4 * k], b = buf[4 * k + 1], c = buf[4 * k + 2], d = buf[4 * k + 3];
+						packetTri<ANYHIT, COUNT>(S, T, inSub, a, b, c, first + k0 + k, __float_as_int(d.y), key0 + k0 + k);
+					}
+					__builtin_amdgcn_wave_barrier();
+				}
+			}
+			TR(8, 0);
 		} else {   // leaf: bvh.cpp:109-118 / 145-157 for the lanes whose ray passed this leaf's box
 			int32_t at = ~node;
 			for (;;) {
@@ -469,9 +529,8 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, PacketLds& L, 
 // atomics per microsecond (MI355X_MICROARCH.md, row "dequeue"), and one atomic per lane refill made that cursor the
 // bottleneck of the whole launch.  Each wave therefore takes kWorkChunk consecutive indices per atomic into a
 // wave-local pool and refills its idle lanes from the pool.
-__device__ __forceinline__ uint32_t waveNumber() { return (blockIdx.x * kBlock + threadIdx.x) >> 6; }
-__device__ __forceinline__ uint32_t waveCount() { return gridDim.x * (kBlock / 64); }
 constexpr uint32_t kWorkChunk = 128;
+constexpr uint32_t kPacketGroup = 8;
 struct WorkPool { uint32_t next, end; bool drained; };
 
 __device__ __forceinline__ uint32_t fetchWork(bool need, WorkPool& pool, uint32_t* head, unsigned long long total) {
@@ -597,13 +656,22 @@ __device__ __forceinline__ uint32_t fetchPacket(uint32_t* head, uint32_t nPacket
 
 // Nearest hit for coherent ray sets: one packet = 64 consecutive queue slots (an 8x8 pixel block of the tile order).
 template <bool CSG, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_intersect_packet(DevScene S, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
-	__shared__ PacketLds lds[kBlock / 64];
+__global__ __launch_bounds__(kBlock) void k_intersect_packet(DevScene S, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr, uint32_t groupStride) {
 	const uint32_t lane = __lane_id();
-	PacketLds& ws = lds[threadIdx.x >> 6];
-	const uint32_t nPackets = (n + 63u) / 64u;
+	const PacketLds ws = packetLdsInit(S);
+	// Hand-out order: groups of kPacketGroup neighbouring packets, the groups visited with a stride coprime to their
+	// number.  A frame has stretches of packets that cost nothing (sky: every ray misses the root box); handed out in
+	// image order they reach the cursor faster than it can serve them (~90 atomics/us) and the end of the launch ran at
+	// the cursor's pace.  Strided, cheap and expensive packets are in flight together all the time.
+	const uint32_t nGroups = ((n + 63u) / 64u + kPacketGroup - 1u) / kPacketGroup;
+	const uint32_t nPackets = nGroups * kPacketGroup;   // the last group may hold empty packets
+	auto permute = [&](uint32_t k) {
+		if (k == kInactive) return k;
+		const uint32_t g = (uint32_t)(((unsigned long long)(k / kPacketGroup) * groupStride) % nGroups);
+		return g * kPacketGroup + k % kPacketGroup;
+	};
 	unsigned long long cn = 0, cp = 0;
-	PROF_DECL
+	TR_DECL(0)
 	struct Rays { f3 e, d; bool alive; };
 	auto loadRays = [&](uint32_t pk) {
 		Rays r;
@@ -618,32 +686,27 @@ __global__ __launch_bounds__(kBlock) void k_intersect_packet(DevScene S, RtQueue
 		}
 		return r;
 	};
-	uint32_t pk = waveNumber() < nPackets ? waveNumber() : kInactive;
+	uint32_t pk = permute(waveNumber() < nPackets ? waveNumber() : kInactive);
 	while (pk != kInactive) {
-		PROF_ADD(6, 1);
+		TR(1, pk);
 		const Rays cur = loadRays(pk);
 		const uint32_t idx = pk * 64u + lane;
 		Trav T;
 		T.cur = kEmpty; T.best = RT_NO_HIT; T.tmin = 0; T.bestTag = 0; T.cntNodes = 0; T.cntPrims = 0;
 		if (cur.alive) travInit<false>(S, T, cur.e, cur.d);
-#if RT_PROF
-		if (__ballot(T.tmin > 1e30f)) pf[5] += 1;   // keeps the ray loads ahead of the lap
-		PROF_LAP(1);
-		{ const unsigned long long s3 = pf[3], s4 = pf[4]; packetTraverse<false, CSG, COUNT>(S, ws, T, cur.alive, pf); PROF_LAP(2); pf[2] -= (pf[3] - s3) + (pf[4] - s4); }
-#else
-		packetTraverse<false, CSG, COUNT>(S, ws, T, cur.alive);
-#endif
-		pk = fetchPacket(&ctr->head_nearest, nPackets);
-		PROF_LAP(0);
+		TR(2, __popcll(__ballot(T.cur != kEmpty)));
+		packetTraverse<false, CSG, COUNT>(S, ws, T, cur.alive TR_ARG);
+		TR(9, 0);
+		pk = permute(fetchPacket(&ctr->head_nearest, nPackets));
+		TR(10, 0);
 		if (idx < n) {
 			qsu(hq, HQ_PRIM, idx, cur.alive ? T.best : RT_NO_HIT);
 			qsf(hq, HQ_T, idx, (cur.alive && T.best != RT_NO_HIT) ? T.tmin : 0.0f);
 			if (CSG) qsu(hq, HQ_TAG, idx, T.bestTag);
 		}
 		if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
-		PROF_LAP(5);
+		TR(11, 0);
 	}
-	PROF_FLUSH(0);
 	if (COUNT) { atomicAdd(&ctr->nodes_nearest, cn); atomicAdd(&ctr->prims_nearest, cp); }
 }
 
@@ -921,13 +984,12 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq,
 template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_shadow_point_packet(DevScene S, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                                                                 RtAccum A, uint32_t aaSq, RtCounters* ctr) {
-	__shared__ PacketLds lds[kBlock / 64];
 	const uint32_t lane = __lane_id();
-	PacketLds& ws = lds[threadIdx.x >> 6];
+	const PacketLds ws = packetLdsInit(S);
 	const uint32_t packetsPerLight = (nsurf + 63u) / 64u;
 	const uint32_t totalPackets = packetsPerLight * nLights;
 	unsigned long long cn = 0, cp = 0;
-	PROF_DECL
+	TR_DECL(1)
 	// light-minor numbering: the packets of one group of 64 surfaces towards every light are neighbours
 	auto surfaceOf = [&](uint32_t q) { return (q / nLights) * 64u + lane; };
 	auto loadPoint = [&](uint32_t q) {
@@ -940,7 +1002,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point_packet(DevScene S, RtQu
 	};
 	uint32_t q = waveNumber() < totalPackets ? waveNumber() : kInactive;
 	while (q != kInactive) {
-		PROF_ADD(6, 1);
+		TR(1, q);
 		const f3 p = loadPoint(q);
 		const int lightIndex = lightList[q % nLights];
 		const uint32_t s = surfaceOf(q);
@@ -952,15 +1014,11 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point_packet(DevScene S, RtQu
 			pointLightGeometry(S.lights[lightIndex], p, Ld, lightPos);
 			travInit<true>(S, T, p, lightPos - p);   // bvh.cpp:124
 		}
-#if RT_PROF
-		if (__ballot(T.len > 1e30f)) pf[5] += 1;
-		PROF_LAP(1);
-		{ const unsigned long long s3 = pf[3], s4 = pf[4]; packetTraverse<true, CSG, COUNT>(S, ws, T, alive, pf); PROF_LAP(2); pf[2] -= (pf[3] - s3) + (pf[4] - s4); }
-#else
-		packetTraverse<true, CSG, COUNT>(S, ws, T, alive);
-#endif
+		TR(2, __popcll(__ballot(T.cur != kEmpty)));
+		packetTraverse<true, CSG, COUNT>(S, ws, T, alive TR_ARG);
+		TR(9, 0);
 		q = fetchPacket(&ctr->head_shadow, totalPackets);
-		PROF_LAP(0);
+		TR(10, 0);
 		if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
 		if (alive && T.lit) {
 			const rt_light L = S.lights[lightIndex];
@@ -972,9 +1030,8 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point_packet(DevScene S, RtQu
 				accumAdd(A, sf.pixKey / aaSq, sf.w * c);
 			}
 		}
-		PROF_LAP(5);
+		TR(11, 0);
 	}
-	PROF_FLUSH(8);
 	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
 }
 
@@ -984,7 +1041,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point_packet(DevScene S, RtQu
 template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t seed,
                                                         RtAccum A, uint32_t aaSq, RtCounters* ctr) {
-	__shared__ PacketLds lds[kBlock / 64];
+	const PacketLds ws = packetLdsInit(S);
 	const rt_light L = S.lights[lightIndex];
 	const uint32_t ns = (uint32_t)L.samples;
 	const unsigned long long j = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
@@ -1015,7 +1072,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, 
 		lightPos = ld3(L.position) + ld3(L.planeX) * xDisplacement + ld3(L.planeY) * yDisplacement;
 		travInit<true>(S, T, sf.p, lightPos - sf.p);
 	}
-	packetTraverse<true, CSG, COUNT>(S, lds[threadIdx.x >> 6], T, live);
+	packetTraverse<true, CSG, COUNT>(S, ws, T, live);
 	if (live) {
 		if (COUNT) { atomicAdd(&ctr->nodes_shadow, T.cntNodes); atomicAdd(&ctr->prims_shadow, T.cntPrims); }
 		if (T.lit) c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
@@ -1100,10 +1157,14 @@ static int computeUnits() {
 	if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
 	return cus;
 }
-#define RT_LAUNCH_P(kernel, n, maxBlocks, stream, ...) do { if ((n) > 0) { \
-		static int _perCU = 0; \
-		if (!_perCU && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&_perCU, kernel, kBlock, 0) != hipSuccess || _perCU <= 0)) _perCU = 1; \
-		hipLaunchKernelGGL(kernel, dim3(gridPersistent(n, std::min(maxBlocks, _perCU * computeUnits()))), dim3(kBlock), 0, stream, __VA_ARGS__); } } while (0)
+#define RT_LAUNCH_PS(kernel, n, maxBlocks, lds, stream, ...) do { if ((n) > 0) { \
+		static int _perCU = 0; static size_t _lds = ~(size_t)0; \
+		if (_lds != (size_t)(lds)) { _lds = (size_t)(lds); if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&_perCU, kernel, kBlock, _lds) != hipSuccess || _perCU <= 0) _perCU = 1; \
+			if (getenv("RT_DEBUG_GRID")) fprintf(stderr, "[grid] %s: %d workgroups/CU resident with %zu B LDS\n", #kernel, _perCU, _lds); } \
+		hipLaunchKernelGGL(kernel, dim3(gridPersistent(n, std::min(maxBlocks, _perCU * computeUnits()))), dim3(kBlock), _lds, stream, __VA_ARGS__); } } while (0)
+#define RT_LAUNCH_P(kernel, n, maxBlocks, stream, ...) RT_LAUNCH_PS(kernel, n, maxBlocks, 0, stream, __VA_ARGS__)
+#define RT_LAUNCH_S(kernel, n, lds, stream, ...) do { if ((n) > 0) hipLaunchKernelGGL(kernel, dim3(gridFor(n)), dim3(kBlock), lds, stream, __VA_ARGS__); } while (0)
+static size_t packetLdsBytes(const DevScene& S) { return (size_t)RT_PACKET_LDS_BYTES(S.treelet_levels, S.treelet_staging); }
 
 void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, int aaY, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq) {
 	RT_LAUNCH(k_generate, count, st, cam, W, H, aaX, aaY, tileRank, tileRanks, r0, count, rq);
@@ -1111,10 +1172,20 @@ void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, i
 void rtk_load_rays(hipStream_t st, const float* a, const float* b, uint32_t n, int bIsTarget, RtQueue rq, uint32_t pixBase) {
 	RT_LAUNCH(k_load_rays, n, st, a, b, n, bIsTarget, rq, pixBase);
 }
+// a stride near the golden section of `groups` and coprime to it: consecutive hand-outs land far apart, every group is visited once
+static uint32_t coprimeStride(uint32_t groups) {
+	if (groups < 3) return 1;
+	auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+	uint32_t s = (uint32_t)((double)groups * 0.6180339887498949);
+	if (s < 1) s = 1;
+	while (gcd(s, groups) != 1) s++;
+	return s % groups ? s % groups : 1;
+}
 void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
 	if (coherent) {
-		if (csg) { if (count) RT_LAUNCH_P((k_intersect_packet<true, true>), n, maxBlocks, st, S, rq, n, hq, ctr); else RT_LAUNCH_P((k_intersect_packet<true, false>), n, maxBlocks, st, S, rq, n, hq, ctr); }
-		else { if (count) RT_LAUNCH_P((k_intersect_packet<false, true>), n, maxBlocks, st, S, rq, n, hq, ctr); else RT_LAUNCH_P((k_intersect_packet<false, false>), n, maxBlocks, st, S, rq, n, hq, ctr); }
+		const uint32_t stride = coprimeStride(((n + 63u) / 64u + kPacketGroup - 1u) / kPacketGroup);
+		if (csg) { if (count) RT_LAUNCH_PS((k_intersect_packet<true, true>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, hq, ctr, stride); else RT_LAUNCH_PS((k_intersect_packet<true, false>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, hq, ctr, stride); }
+		else { if (count) RT_LAUNCH_PS((k_intersect_packet<false, true>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, hq, ctr, stride); else RT_LAUNCH_PS((k_intersect_packet<false, false>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, hq, ctr, stride); }
 		return;
 	}
 	if (csg) { if (count) RT_LAUNCH_P((k_intersect<true, true>), n, maxBlocks, st, S, rq, n, hq, ctr); else RT_LAUNCH_P((k_intersect<true, false>), n, maxBlocks, st, S, rq, n, hq, ctr); }
@@ -1133,8 +1204,8 @@ void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, b
 	const unsigned long long items = (unsigned long long)nsurf * nLights;
 	if (coherent) {
 		const unsigned long long pitems = (unsigned long long)((nsurf + 63u) / 64u) * 64u * nLights;
-		if (csg) { if (count) RT_LAUNCH_P((k_shadow_point_packet<true, true>), pitems, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_P((k_shadow_point_packet<true, false>), pitems, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
-		else { if (count) RT_LAUNCH_P((k_shadow_point_packet<false, true>), pitems, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_P((k_shadow_point_packet<false, false>), pitems, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
+		if (csg) { if (count) RT_LAUNCH_PS((k_shadow_point_packet<true, true>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_PS((k_shadow_point_packet<true, false>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
+		else { if (count) RT_LAUNCH_PS((k_shadow_point_packet<false, true>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_PS((k_shadow_point_packet<false, false>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
 		return;
 	}
 	if (csg) { if (count) RT_LAUNCH_P((k_shadow_point<true, true>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_P((k_shadow_point<true, false>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
@@ -1143,8 +1214,8 @@ void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, b
 void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t samples, uint32_t seed,
                      RtAccum A, uint32_t aaSq, RtCounters* ctr) {
 	const unsigned long long items = (unsigned long long)nsurf * samples;
-	if (csg) { if (count) RT_LAUNCH((k_shadow_area<true, true>), items, st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); else RT_LAUNCH((k_shadow_area<true, false>), items, st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); }
-	else { if (count) RT_LAUNCH((k_shadow_area<false, true>), items, st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); else RT_LAUNCH((k_shadow_area<false, false>), items, st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); }
+	if (csg) { if (count) RT_LAUNCH_S((k_shadow_area<true, true>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); else RT_LAUNCH_S((k_shadow_area<true, false>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); }
+	else { if (count) RT_LAUNCH_S((k_shadow_area<false, true>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); else RT_LAUNCH_S((k_shadow_area<false, false>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); }
 }
 void rtk_shadow_query(hipStream_t st, const DevScene& S, bool csg, const float* point, const float* lightPos, uint32_t n, uint8_t* lit, float* shadow) {
 	if (csg) RT_LAUNCH((k_shadow_query<true>), n, st, S, point, lightPos, n, lit, shadow);

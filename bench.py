@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--grid", type=int, default=224, help="height-field cells per side (224 -> 100 352 triangles)")
+    ap.add_argument("--inflight", type=int, default=3, help="frames in flight (rt_render_submit / rt_render_wait); 1 = one synchronous frame at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save", default=None, help="write the last frame as a BMP (rank 0)")
     args = ap.parse_args()
@@ -79,7 +80,9 @@ def main():
     scene = rt.Scene(flat, local_rank)
     cam = rt.Camera(flat.fov, W, H, eye=eye, rot_x=rot_x)
 
-    frame = torch.zeros(H, W, 3, device=dev, dtype=torch.float32)
+    D = max(1, min(3, args.inflight))
+    frames = [torch.zeros(H, W, 3, device=dev, dtype=torch.float32) for _ in range(D)]
+    frame = frames[0]
     ntiles = scene.tiles_count(W, H, rank, world)
     packed = torch.zeros(ntiles * 256 * 3, device=dev, dtype=torch.float32)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -87,33 +90,59 @@ def main():
     sizes = [scene.tiles_count(W, H, r, world) * 256 * 3 for r in range(world)]
     recv = [torch.zeros(n, device=dev, dtype=torch.float32) for n in sizes] if (world > 1 and rank == 0) else None
 
+    def assemble(buf):
+        # tiles -> rank 0 (RCCL gather over xGMI; point-to-point when the tile counts are ragged), then de-interleave
+        scene.tiles_pack(buf.data_ptr(), packed.data_ptr(), W, H, rank, world, stream=stream)
+        bufs = rd.gather_packed(packed, sizes, rank, world, bufs=recv)
+        if rank == 0:
+            for r in range(1, world):
+                scene.tiles_unpack(bufs[r].data_ptr(), buf.data_ptr(), W, H, r, world, stream=stream)
+
     def step(flags=0, max_depth=rt.MAX_REFLECTIONS):
+        """One synchronous frame."""
         st = scene.render_into(frame.data_ptr(), W, H, aa=(ax, ay), camera=cam, tile_rank=rank, tile_ranks=world, stream=stream, flags=flags,
                                max_depth=max_depth)
         if world > 1:
-            # tiles -> rank 0 (RCCL gather over xGMI; point-to-point when the tile counts are ragged), then de-interleave
-            scene.tiles_pack(frame.data_ptr(), packed.data_ptr(), W, H, rank, world, stream=stream)
-            bufs = rd.gather_packed(packed, sizes, rank, world, bufs=recv)
-            if rank == 0:
-                for r in range(1, world):
-                    scene.tiles_unpack(bufs[r].data_ptr(), frame.data_ptr(), W, H, r, world, stream=stream)
+            assemble(frame)
         return st
+
+    def run_steps(k):
+        """k frames with up to D in flight: frame i+1 is queued before frame i is waited for (and, with N > 1 ranks, gathered)."""
+        rays, pending = 0, []
+        def retire():
+            nonlocal rays
+            ticket, buf = pending.pop(0)
+            st = scene.render_wait(ticket)
+            if world > 1:
+                assemble(buf)
+            rays += st["rays_nearest"] + st["rays_shadow"]
+        for i in range(k):
+            if len(pending) == D:
+                retire()
+            buf = frames[i % D]
+            pending.append((scene.render_submit(buf.data_ptr(), W, H, aa=(ax, ay), camera=cam, tile_rank=rank, tile_ranks=world, stream=stream), buf))
+        while pending:
+            retire()
+        return rays
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    rays = 0
-    for _ in range(args.steps):
-        st = step()
-        rays += st["rays_nearest"] + st["rays_shadow"]
+    rays = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    # latency of a frame rendered alone (nothing else in flight), for the record
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        step()
+    barrier()
+    latency_ms = (time.perf_counter() - t1) / 5 * 1e3
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -188,12 +217,13 @@ def main():
 
     if rank == 0:
         if args.save:
-            rt.write_bmp(args.save, frame.cpu().numpy())
+            rt.write_bmp(args.save, frames[(args.steps - 1) % D].cpu().numpy())
         value = rays / elapsed / 1e6
         out = {
             "metric": "Mrays/sec (primary+secondary) at 1080p", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "frames_in_flight": D, "single_frame_latency_ms": round(latency_ms, 4),
             "config": {"workload": f"C2: {flat.info.n_tris}-triangle textured height field + 2 bump spheres, ambient+directional+point light, "
                                    f"{W}x{H}, {ax}x{ay} samples/pixel, tiles sharded over {world} GPU(s)",
                        "width": W, "height": H, "samples_per_pixel": ax * ay, "rays_per_step": rays // args.steps,

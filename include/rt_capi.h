@@ -12,7 +12,8 @@
  *     call returns after it has completed unless the function says otherwise.
  *   - vec3 arrays are tightly packed xyz floats (layout-compatible with glm::vec3[], raytracer.h:9-10).
  *   - one rt_scene per (scene, device); calls on DIFFERENT handles may run concurrently, calls on one handle
- *     must not (the handle owns its queues).
+ *     must come from one thread at a time (the handle owns its queues); rt_render_submit / rt_render_wait keep
+ *     several frames of one handle in flight.
  */
 #ifndef RT_CAPI_H
 #define RT_CAPI_H
@@ -104,7 +105,22 @@ void rt_scene_free(rt_scene* scene);
  * Enqueues on `stream`, waits for completion, fills *stats if not NULL. */
 int rt_render(rt_scene* scene, const rt_camera* camera, int width, int height, int aa_x, int aa_y, int max_depth,
               int tile_rank, int tile_ranks, uint32_t seed, uint32_t flags, float* rgb_dev, void* stream, rt_stats* stats);
-/* Convenience: same, into a HOST buffer (allocates a temporary device frame). */
+/* The same frame, asynchronously.  New: the reference renders one pixel at a time on one thread; this is the form a
+ * caller that streams frames (the reference's GLUT idle loop, a camera path, one frame per GPU rank) uses to keep
+ * the GPU full.  rt_render_submit queues the frame and returns at once with a ticket; rt_render_wait blocks until that
+ * frame is complete in rgb_dev, makes `stream` (the one given at submit) wait for it, and fills *stats.  rt_render is
+ * submit + wait.  Inside, a frame is cut into interleaved tile shards that run on the handle's own HIP streams
+ * ("lanes", RT_LANES, default 4), each driven by its own host thread; shards never wait for each other, so the long
+ * tail of one shard's kernels is filled by the next shard -- of the same frame or of the next frame in flight.
+ *   - at most 4 tickets may be outstanding; tickets are waited for in any order, each exactly once
+ *   - frames in flight must write to DIFFERENT rgb_dev buffers
+ *   - a frame with another size / tile split than the ones in flight, or with RT_FLAG_COUNTERS / RT_FLAG_TIME_KERNELS,
+ *     first lets the lanes run dry (it is still correct, only not overlapped)
+ *   - the other entry points of this header wait for outstanding frames before they run */
+int rt_render_submit(rt_scene* scene, const rt_camera* camera, int width, int height, int aa_x, int aa_y, int max_depth,
+                     int tile_rank, int tile_ranks, uint32_t seed, uint32_t flags, float* rgb_dev, void* stream, uint64_t* ticket);
+int rt_render_wait(rt_scene* scene, uint64_t ticket, rt_stats* stats);
+/* Convenience: rt_render into a HOST buffer (allocates a temporary device frame). */
 int rt_render_host(rt_scene* scene, const rt_camera* camera, int width, int height, int aa_x, int aa_y, int max_depth,
                    uint32_t seed, uint32_t flags, float* rgb_host, rt_stats* stats);
 

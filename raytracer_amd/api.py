@@ -116,6 +116,23 @@ class Scene:
         self.last_stats = st.as_dict()
         return self.last_stats
 
+    def render_submit(self, frame_dev_ptr, width, height, aa=1, max_depth=capi.MAX_REFLECTIONS, seed=1, flags=0, camera=None,
+                      tile_rank=0, tile_ranks=1, stream=None):
+        """Queues a frame (rt_render_submit) and returns its ticket; at most 4 may be outstanding, each into its own buffer."""
+        cam = camera or self.camera(width, height)
+        ax, ay = _aa(aa)
+        ticket = C.c_uint64(0)
+        check(capi.load().rt_render_submit(self._h, C.byref(cam.c), width, height, ax, ay, max_depth, tile_rank, tile_ranks, seed, flags,
+                                           C.c_void_p(frame_dev_ptr), C.c_void_p(stream or 0), C.byref(ticket)))
+        return int(ticket.value)
+
+    def render_wait(self, ticket):
+        """Blocks until the frame of `ticket` is complete (rt_render_wait); returns its stats."""
+        st = rt_stats()
+        check(capi.load().rt_render_wait(self._h, C.c_uint64(ticket), C.byref(st)))
+        self.last_stats = st.as_dict()
+        return self.last_stats
+
     def trace_batch(self, e, s, max_depth=capi.MAX_REFLECTIONS, seed=1, flags=0):
         """trace() for n rays (raytracer.cpp:307): returns dict(hit, id, t, rgb)."""
         e, s = f32(e, (-1, 3)), f32(s, (-1, 3))

@@ -19,7 +19,7 @@ MAX_REFLECTIONS = 16
 SYMBOLS = [
     "rt_load_scene_json", "rt_load_scene_json_text", "rt_flat_scene_save", "rt_flat_scene_load", "rt_flat_scene_free",
     "rt_camera_setup", "rt_write_bmp", "rt_quantize_rgb8", "rt_device_count", "rt_scene_upload", "rt_scene_free",
-    "rt_render", "rt_render_host", "rt_trace_batch", "rt_intersect_batch", "rt_shadow_batch", "rt_tiles_merge",
+    "rt_render", "rt_render_submit", "rt_render_wait", "rt_render_host", "rt_trace_batch", "rt_intersect_batch", "rt_shadow_batch", "rt_tiles_merge",
     "rt_tiles_count", "rt_tiles_pack", "rt_tiles_unpack", "rt_last_error", "rt_version",
 ]
 
@@ -87,6 +87,9 @@ def load():
     lib.rt_scene_free.restype = None
     lib.rt_render.argtypes = [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                               C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]
+    lib.rt_render_submit.argtypes = [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.rt_render_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(rt_stats)]
     lib.rt_render_host.argtypes = [C.c_void_p, C.POINTER(rt_camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                                    C.c_void_p, C.POINTER(rt_stats)]
     lib.rt_trace_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32,

@@ -9,12 +9,20 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
 
 namespace {
 
+#define RT_MAX_LANES 8
+#define RT_MAX_INFLIGHT 4
 #define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rt::set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); return RT_EHIP; } } while (0)
 
 uint32_t envU32(const char* name, uint32_t dflt) {
@@ -36,14 +44,47 @@ struct rt_scene {
 	uint32_t nPointLights = 0;
 	std::vector<std::pair<int, uint32_t>> areaLights;   // (light index, samples)
 	uint64_t shadowRaysPerSurface = 0;
-	// queues
+	// A lane = everything one in-flight pixel batch needs: its queues, counters, events and (lanes > 0) its own stream.
+	// A frame is rendered as `lanes.size()` interleaved tile shards at once, one per lane, each driven by its own
+	// host thread: the kernels of a level have long tails (a few packets walk ten times the average), and with several
+	// independent shards in flight the tail of one kernel is filled by the kernels of the others.
+	struct Lane {
+		RtQueue ray[2]{}, hitq{}, surfq{};
+		RtCounters* ctr = nullptr;       // device
+		RtCounters* ctrHost = nullptr;   // pinned
+		hipEvent_t ev[6]{};              // 0,1 whole call; 2,3 nearest kernel; 4,5 shadow kernels
+		hipStream_t stream = nullptr;    // owned, non-blocking (lane 0 also runs on the caller's stream)
+	};
 	uint32_t qcap = 0;
-	int maxBlocks = 2048;            // grid of the persistent kernels: 8 workgroups per CU
-	RtQueue ray[2]{}, hitq{}, surfq{};
-	RtCounters* ctr = nullptr;       // device
-	RtCounters* ctrHost = nullptr;   // pinned
+	int maxBlocks = 2048;            // grid cap of the persistent kernels
+	std::vector<Lane> lanes;
 	RtAccum accum{};
-	hipEvent_t ev[6]{};              // 0,1 whole call; 2,3 nearest kernel; 4,5 shadow kernels
+	// Frames are rendered asynchronously: rt_render_submit queues one shard of the frame on every lane (shard k = the
+	// tiles t of the call with t % (tile_ranks * lanes) == tile_rank + tile_ranks * k), each lane's worker thread drives
+	// its shards in submission order, and rt_render_wait joins them.  Lanes never wait for each other, so the tail of
+	// one shard's kernels overlaps the next shard -- of the same frame or, with several frames in flight, of the next.
+	struct Job {
+		uint64_t id = 0;                 // 0 = slot free
+		rt_camera cam{};
+		int W = 0, H = 0, aaX = 1, aaY = 1, maxDepth = 0, tileRank = 0, tileRanks = 1, nShards = 1;
+		uint32_t seed = 0, flags = 0;
+		float* rgb = nullptr;
+		hipStream_t st = nullptr;
+		hipEvent_t evStart = nullptr, evEnd = nullptr, evDone[RT_MAX_LANES]{};
+		int remaining = 0;               // lanes that have not finished their part yet
+		int rc[RT_MAX_LANES]{};
+		std::string err[RT_MAX_LANES];
+		rt_stats part[RT_MAX_LANES]{};
+	};
+	Job jobs[RT_MAX_INFLIGHT];
+	uint64_t nextId = 1;
+	std::deque<Job*> laneQueue[RT_MAX_LANES];
+	std::vector<std::thread> workers;
+	std::mutex mtx;
+	std::condition_variable cvWork, cvDone;
+	bool stopping = false;
+	hipEvent_t lane0Last = nullptr;      // end of lane 0's previous shard and the stream it ran on (lane 0's worker only)
+	hipStream_t lane0LastStream = nullptr;
 
 	template <class T> int upload(const T* src, int64_t count, const T** dst) {
 		*dst = nullptr;
@@ -63,6 +104,24 @@ struct rt_scene {
 		q.f = static_cast<float*>(p); q.cap = qcap;
 		return RT_OK;
 	}
+	int initLane(Lane& ln, bool ownStream) {
+		if (int rc = allocQueue(ln.ray[0], RQ_COMPS)) return rc;
+		if (int rc = allocQueue(ln.ray[1], RQ_COMPS)) return rc;
+		if (int rc = allocQueue(ln.hitq, HQ_COMPS)) return rc;
+		if (int rc = allocQueue(ln.surfq, SQ_COMPS)) return rc;
+		void* p = nullptr;
+		HIPCHK(hipMalloc(&p, sizeof(RtCounters)));
+		allocs.push_back(p);
+		ln.ctr = static_cast<RtCounters*>(p);
+		HIPCHK(hipHostMalloc((void**)&ln.ctrHost, sizeof(RtCounters), hipHostMallocDefault));
+		for (auto& e : ln.ev) HIPCHK(hipEventCreate(&e));
+		if (ownStream) HIPCHK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+		return RT_OK;
+	}
+	int inFlight() const { int n = 0; for (const Job& j : jobs) if (j.id && j.remaining > 0) n++; return n; }
+	// waits until the lanes are idle (jobs may still be un-waited-for); call with mtx held
+	void drainLocked(std::unique_lock<std::mutex>& g) { cvDone.wait(g, [&] { return inFlight() == 0; }); }
+	void drain() { std::unique_lock<std::mutex> g(mtx); drainLocked(g); }
 	int ensureAccum(uint32_t npix) {
 		if (accum.npix >= npix && accum.rgb) return RT_OK;
 		if (accum.rgb) { (void)hipFree(accum.rgb); (void)hipFree(accum.nonfinite); accum.rgb = nullptr; accum.nonfinite = nullptr; accum.npix = 0; }
@@ -193,7 +252,7 @@ struct Source {
 };
 
 struct Run {
-	rt_scene* sc; hipStream_t st; Source src; int maxDepth; uint32_t seed; uint32_t flags; uint32_t aaSq;
+	rt_scene* sc; rt_scene::Lane* ln; hipStream_t st; Source src; int maxDepth; uint32_t seed; uint32_t flags; uint32_t aaSq;
 	rt_stats stats{};
 
 	// Which traversal form a level uses.  Level 0 of a frame (and its shadow rays) is coherent by construction: 64
@@ -203,7 +262,7 @@ struct Run {
 
 	int syncCounters() {
 		HIPCHK(hipGetLastError());
-		HIPCHK(hipMemcpyAsync(sc->ctrHost, sc->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost, st));
+		HIPCHK(hipMemcpyAsync(ln->ctrHost, ln->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost, st));
 		HIPCHK(hipStreamSynchronize(st));
 		return RT_OK;
 	}
@@ -212,43 +271,43 @@ struct Run {
 	int levels(uint32_t r0, uint32_t cnt) {
 		const bool count = (flags & RT_FLAG_COUNTERS) != 0, timeK = (flags & RT_FLAG_TIME_KERNELS) != 0;
 		int cur = 0;
-		if (src.camera) rtk_generate(st, src.cam, src.W, src.H, src.aaX, src.aaY, src.tileRank, src.tileRanks, r0, cnt, sc->ray[0]);
-		else rtk_load_rays(st, src.a + 3 * (size_t)r0, src.b + 3 * (size_t)r0, cnt, 1, sc->ray[0], r0);
+		if (src.camera) rtk_generate(st, src.cam, src.W, src.H, src.aaX, src.aaY, src.tileRank, src.tileRanks, r0, cnt, ln->ray[0]);
+		else rtk_load_rays(st, src.a + 3 * (size_t)r0, src.b + 3 * (size_t)r0, cnt, 1, ln->ray[0], r0);
 		uint32_t n = cnt;
 		bool shadowPending = false;
 		uint64_t nearRays = 0, shadowRays = 0, nLevels = 0;
 		for (int level = 0; level <= maxDepth && n > 0; level++) {
-			HIPCHK(hipMemsetAsync(sc->ctr, 0, RT_COUNTER_RESET_BYTES, st));   // queue counts and work cursors
-			if (timeK) HIPCHK(hipEventRecord(sc->ev[2], st));
-			rtk_intersect(st, sc->dev, sc->hasCsg, count, coherent(level), sc->maxBlocks, sc->ray[cur], n, sc->hitq, sc->ctr);
-			if (timeK) HIPCHK(hipEventRecord(sc->ev[3], st));
-			rtk_shade(st, sc->dev, sc->hasCsg, sc->ray[cur], sc->hitq, n, sc->ray[cur ^ 1], sc->surfq, sc->ctr, sc->accum, aaSq, maxDepth,
+			HIPCHK(hipMemsetAsync(ln->ctr, 0, RT_COUNTER_RESET_BYTES, st));   // queue counts and work cursors
+			if (timeK) HIPCHK(hipEventRecord(ln->ev[2], st));
+			rtk_intersect(st, sc->dev, sc->hasCsg, count, coherent(level), sc->maxBlocks, ln->ray[cur], n, ln->hitq, ln->ctr);
+			if (timeK) HIPCHK(hipEventRecord(ln->ev[3], st));
+			rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, n, ln->ray[cur ^ 1], ln->surfq, ln->ctr, sc->accum, aaSq, maxDepth,
 			          sc->shadowRaysPerSurface > 0, level == 0 ? src.outHit : nullptr, src.outId, src.outT);
 			if (int rc = syncCounters()) return rc;
 			if (timeK) {
 				float ms = 0;
-				HIPCHK(hipEventElapsedTime(&ms, sc->ev[2], sc->ev[3])); stats.nearest_ms += ms;
-				if (shadowPending) { HIPCHK(hipEventElapsedTime(&ms, sc->ev[4], sc->ev[5])); stats.shadow_ms += ms; shadowPending = false; }
+				HIPCHK(hipEventElapsedTime(&ms, ln->ev[2], ln->ev[3])); stats.nearest_ms += ms;
+				if (shadowPending) { HIPCHK(hipEventElapsedTime(&ms, ln->ev[4], ln->ev[5])); stats.shadow_ms += ms; shadowPending = false; }
 			}
-			if (sc->ctrHost->overflow) return 1;
+			if (ln->ctrHost->overflow) return 1;
 			nLevels++;
 			// inactive slots of a partial edge tile are not rays
 			nearRays += n;
-			const uint32_t nsurf = sc->ctrHost->surf_count;
+			const uint32_t nsurf = ln->ctrHost->surf_count;
 			if (nsurf > 0 && sc->shadowRaysPerSurface > 0) {
-				if (timeK) HIPCHK(hipEventRecord(sc->ev[4], st));
-				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, coherent(level), sc->maxBlocks, sc->surfq, nsurf, sc->pointLights, sc->nPointLights, sc->accum, aaSq, sc->ctr);
-				for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, count, sc->surfq, nsurf, al.first, al.second, seed, sc->accum, aaSq, sc->ctr);
-				if (timeK) { HIPCHK(hipEventRecord(sc->ev[5], st)); shadowPending = true; }
+				if (timeK) HIPCHK(hipEventRecord(ln->ev[4], st));
+				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, coherent(level), sc->maxBlocks, ln->surfq, nsurf, sc->pointLights, sc->nPointLights, sc->accum, aaSq, ln->ctr);
+				for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, count, ln->surfq, nsurf, al.first, al.second, seed, sc->accum, aaSq, ln->ctr);
+				if (timeK) { HIPCHK(hipEventRecord(ln->ev[5], st)); shadowPending = true; }
 				shadowRays += (uint64_t)nsurf * sc->shadowRaysPerSurface;
 			}
-			n = sc->ctrHost->next_count;
+			n = ln->ctrHost->next_count;
 			cur ^= 1;
 		}
 		if (shadowPending) {
 			float ms = 0;
-			HIPCHK(hipEventSynchronize(sc->ev[5]));
-			HIPCHK(hipEventElapsedTime(&ms, sc->ev[4], sc->ev[5])); stats.shadow_ms += ms;
+			HIPCHK(hipEventSynchronize(ln->ev[5]));
+			HIPCHK(hipEventElapsedTime(&ms, ln->ev[4], ln->ev[5])); stats.shadow_ms += ms;
 		}
 		stats.rays_nearest += nearRays; stats.rays_shadow += shadowRays; stats.levels = std::max<uint64_t>(stats.levels, nLevels);
 		return RT_OK;
@@ -261,7 +320,7 @@ struct Run {
 		if (rc != 1) return rc;
 		stats = saved;
 		stats.batch_splits++;
-		HIPCHK(hipMemsetAsync(&sc->ctr->overflow, 0, sizeof(uint32_t), st));
+		HIPCHK(hipMemsetAsync(&ln->ctr->overflow, 0, sizeof(uint32_t), st));
 		// clear this batch's pixels (resolve with no destination only zeroes the accumulators)
 		rtk_resolve(st, sc->accum, src.W, src.H, src.tileRank, src.tileRanks, r0 / aaSq, cnt / aaSq, aaSq, src.camera ? 0 : 1, nullptr);
 		if (cnt <= aaSq) { rt::set_error("ray queue too small for the ray tree of a single pixel (raise RT_QUEUE_RAYS)"); return RT_ELIMIT; }
@@ -280,28 +339,28 @@ struct Run {
 	}
 };
 
-int begin(rt_scene* sc, hipStream_t st, uint32_t flags) {
+int begin(rt_scene* sc, rt_scene::Lane* ln, hipStream_t st, uint32_t flags) {
 	HIPCHK(hipSetDevice(sc->device));
-	HIPCHK(hipMemsetAsync(sc->ctr, 0, sizeof(RtCounters), st));
-	HIPCHK(hipEventRecord(sc->ev[0], st));
+	HIPCHK(hipMemsetAsync(ln->ctr, 0, sizeof(RtCounters), st));
+	HIPCHK(hipEventRecord(ln->ev[0], st));
 	(void)flags;
 	return RT_OK;
 }
-int finish(rt_scene* sc, hipStream_t st, Run& run, rt_stats* stats) {
-	HIPCHK(hipEventRecord(sc->ev[1], st));
-	if (run.flags & RT_FLAG_COUNTERS) HIPCHK(hipMemcpyAsync(sc->ctrHost, sc->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost, st));
+int finish(rt_scene* sc, rt_scene::Lane* ln, hipStream_t st, Run& run, rt_stats* stats) {
+	HIPCHK(hipEventRecord(ln->ev[1], st));
+	if (run.flags & RT_FLAG_COUNTERS) HIPCHK(hipMemcpyAsync(ln->ctrHost, ln->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
-	HIPCHK(hipEventElapsedTime(&run.stats.gpu_ms, sc->ev[0], sc->ev[1]));
+	HIPCHK(hipEventElapsedTime(&run.stats.gpu_ms, ln->ev[0], ln->ev[1]));
 	if (run.flags & RT_FLAG_COUNTERS) {
-		run.stats.nodes_nearest = sc->ctrHost->nodes_nearest; run.stats.prims_nearest = sc->ctrHost->prims_nearest;
-		run.stats.nodes_shadow = sc->ctrHost->nodes_shadow; run.stats.prims_shadow = sc->ctrHost->prims_shadow;
-		run.stats.max_walk = (float)sc->ctrHost->pad;   // longest nearest-hit walk of the call, in nodes (diagnostic)
+		run.stats.nodes_nearest = ln->ctrHost->nodes_nearest; run.stats.prims_nearest = ln->ctrHost->prims_nearest;
+		run.stats.nodes_shadow = ln->ctrHost->nodes_shadow; run.stats.prims_shadow = ln->ctrHost->prims_shadow;
+		run.stats.max_walk = (float)ln->ctrHost->pad;   // longest nearest-hit walk of the call, in nodes (diagnostic)
 	}
 #if RT_PROF
 	if (const char* path = getenv("RT_TRACE_FILE")) {   // raw dump of RtCounters::trace (tools/trace_summary.py)
 		std::vector<RtCounters> c(1);
-		HIPCHK(hipMemcpy(c.data(), sc->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost));
-		if (FILE* f = fopen(path, "wb")) { fwrite(c[0].trace, sizeof c[0].trace, 1, f); fclose(f); }
+		HIPCHK(hipMemcpy(c.data(), ln->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost));
+		if (FILE* f = fopen(path, "wb")) { fwrite(c[0].trace, sizeof c[0].trace, 1, f); fwrite(c[0].waveLog, sizeof c[0].waveLog, 1, f); fclose(f); }
 	}
 #endif
 	if (stats) *stats = run.stats;
@@ -321,6 +380,68 @@ int64_t ownedPixels(int W, int H, int rank, int ranks) {
 		n += std::min<int64_t>(32, W - tx * 32) * std::min<int64_t>(8, H - ty * 8);
 	}
 	return n;
+}
+
+// One shard of a frame on one lane (the lane's worker thread).
+int renderShard(rt_scene* sc, rt_scene::Job* job, int k) {
+	rt_scene::Lane* ln = &sc->lanes[k];
+	// Lane 0 works on the caller's stream: the GPU exposes 4 hardware queues to a process, and a fifth stream in use
+	// (the caller's, which at least carries the start and end events) made two lanes share one queue and run at half
+	// speed.  Its previous shard may have gone to another stream: order them.
+	hipStream_t st = ln->stream;
+	if (k == 0 && getenv("RT_LANE0_OWN_STREAM") == nullptr) {
+		st = job->st;
+		if (sc->lane0Last && sc->lane0LastStream != st) HIPCHK(hipStreamWaitEvent(st, sc->lane0Last, 0));
+		sc->lane0Last = job->evDone[0]; sc->lane0LastStream = st;
+	}
+	HIPCHK(hipStreamWaitEvent(st, job->evStart, 0));
+	if (int rc = begin(sc, ln, st, job->flags)) return rc;
+	const int vr = job->tileRank + job->tileRanks * k, vn = job->tileRanks * job->nShards;
+	const uint32_t aaSq = (uint32_t)(job->aaX * job->aaY);
+	Run run{ sc, ln, st, {}, job->maxDepth, job->seed, job->flags, aaSq };
+	run.src.camera = true; run.src.cam = job->cam; run.src.W = job->W; run.src.H = job->H; run.src.aaX = job->aaX; run.src.aaY = job->aaY;
+	run.src.tileRank = vr; run.src.tileRanks = vn;
+	const uint64_t localPix = (uint64_t)localTiles(job->W, job->H, vr, vn) * 256;
+	if (int rc = run.all(localPix * aaSq)) return rc;
+	rtk_resolve(st, sc->accum, job->W, job->H, vr, vn, 0, (uint32_t)localPix, aaSq, 0, job->rgb);
+	// the padding slots of partial edge tiles went through the first level as inactive lanes: they are not rays
+	run.stats.rays_nearest -= (localPix - (uint64_t)ownedPixels(job->W, job->H, vr, vn)) * aaSq;
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(job->evDone[k], st));
+	if (job->flags & (RT_FLAG_COUNTERS | RT_FLAG_TIME_KERNELS)) { if (int rc = finish(sc, ln, st, run, &job->part[k])) return rc; }
+	else job->part[k] = run.stats;
+	return RT_OK;
+}
+
+void laneWorker(rt_scene* sc, int k) {
+	(void)hipSetDevice(sc->device);
+	for (;;) {
+		rt_scene::Job* job = nullptr;
+		{
+			std::unique_lock<std::mutex> g(sc->mtx);
+			sc->cvWork.wait(g, [&] { return sc->stopping || !sc->laneQueue[k].empty(); });
+			if (sc->laneQueue[k].empty()) return;   // stopping
+			job = sc->laneQueue[k].front();
+			sc->laneQueue[k].pop_front();
+		}
+		if (k < job->nShards) {
+			static const bool dbg = getenv("RT_DEBUG_LANES") != nullptr;
+			static const auto epoch = std::chrono::steady_clock::now();
+			const double t0 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - epoch).count();
+			job->rc[k] = renderShard(sc, job, k);
+			if (job->rc[k]) job->err[k] = rt_last_error();
+			if (dbg) {
+				(void)hipEventSynchronize(job->evDone[k]);
+				const double t1 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - epoch).count();
+				fprintf(stderr, "[lane %d] job %llu: %.0f .. %.0f us (%.0f)\n", k, (unsigned long long)job->id, t0, t1, t1 - t0);
+			}
+		}
+		{
+			std::lock_guard<std::mutex> g(sc->mtx);
+			job->remaining--;
+		}
+		sc->cvDone.notify_all();
+	}
 }
 
 struct DevBuf {   // scoped device allocation
@@ -407,21 +528,18 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	sc->pointLights = const_cast<int32_t*>(plDev);
 
 	sc->qcap = std::max<uint32_t>(1024, envU32("RT_QUEUE_RAYS", 8u << 20));
-	if ((rc = sc->allocQueue(sc->ray[0], RQ_COMPS))) return fail(rc);
-	if ((rc = sc->allocQueue(sc->ray[1], RQ_COMPS))) return fail(rc);
-	if ((rc = sc->allocQueue(sc->hitq, HQ_COMPS))) return fail(rc);
-	if ((rc = sc->allocQueue(sc->surfq, SQ_COMPS))) return fail(rc);
-	{
-		void* p = nullptr;
-		hipError_t e = hipMalloc(&p, sizeof(RtCounters));
-		if (e != hipSuccess) { rt::set_error("hipMalloc counters failed"); return fail(RT_EHIP); }
-		sc->allocs.push_back(p);
-		sc->ctr = static_cast<RtCounters*>(p);
-		e = hipHostMalloc((void**)&sc->ctrHost, sizeof(RtCounters), hipHostMallocDefault);
-		if (e != hipSuccess) { rt::set_error("hipHostMalloc failed"); return fail(RT_EHIP); }
-		for (auto& ev : sc->ev)
-			if (hipEventCreate(&ev) != hipSuccess) { rt::set_error("hipEventCreate failed"); return fail(RT_EHIP); }
+	const int nLanes = (int)std::min<uint32_t>(RT_MAX_LANES, envU32("RT_LANES", 4));   // the box exposes 4 hardware queues per process
+	sc->lanes.resize(nLanes);
+	// lane 0 runs on the caller's stream (renderShard); creating a stream it would not use would still claim one of
+	// the process's 4 hardware queues and push a working lane onto a shared one
+	for (int i = 0; i < nLanes; i++)
+		if ((rc = sc->initLane(sc->lanes[i], i > 0 || getenv("RT_LANE0_OWN_STREAM") != nullptr))) return fail(rc);
+	for (auto& j : sc->jobs) {
+		bool ok = hipEventCreate(&j.evStart) == hipSuccess && hipEventCreate(&j.evEnd) == hipSuccess;
+		for (int i = 0; i < nLanes && ok; i++) ok = hipEventCreate(&j.evDone[i]) == hipSuccess;
+		if (!ok) { rt::set_error("hipEventCreate failed"); return fail(RT_EHIP); }
 	}
+	for (int i = 0; i < nLanes; i++) sc->workers.emplace_back([sc, i] { laneWorker(sc, i); });
 	*out = sc;
 	return RT_OK;
 }
@@ -432,30 +550,108 @@ void rt_scene_free(rt_scene* sc) {
 	for (void* p : sc->allocs) (void)hipFree(p);
 	if (sc->accum.rgb) (void)hipFree(sc->accum.rgb);
 	if (sc->accum.nonfinite) (void)hipFree(sc->accum.nonfinite);
-	if (sc->ctrHost) (void)hipHostFree(sc->ctrHost);
-	for (auto& ev : sc->ev) if (ev) (void)hipEventDestroy(ev);
+	{
+		std::unique_lock<std::mutex> g(sc->mtx);
+		sc->drainLocked(g);
+		sc->stopping = true;
+	}
+	sc->cvWork.notify_all();
+	for (auto& t : sc->workers) t.join();
+	for (auto& ln : sc->lanes) {
+		if (ln.ctrHost) (void)hipHostFree(ln.ctrHost);
+		for (auto& ev : ln.ev) if (ev) (void)hipEventDestroy(ev);
+		if (ln.stream) (void)hipStreamDestroy(ln.stream);
+	}
+	for (auto& j : sc->jobs) {
+		if (j.evStart) (void)hipEventDestroy(j.evStart);
+		if (j.evEnd) (void)hipEventDestroy(j.evEnd);
+		for (auto& e : j.evDone) if (e) (void)hipEventDestroy(e);
+	}
 	delete sc;
+}
+
+int rt_render_submit(rt_scene* sc, const rt_camera* camera, int width, int height, int aa_x, int aa_y, int max_depth, int tile_rank, int tile_ranks,
+                     uint32_t seed, uint32_t flags, float* rgb_dev, void* stream, uint64_t* ticket) {
+	if (!sc || !camera || !rgb_dev || !ticket || width <= 0 || height <= 0 || aa_x < 1 || aa_x > 16 || aa_y < 1 || aa_y > 16 || max_depth < 0 || max_depth > 30 ||
+	    tile_ranks < 1 || tile_rank < 0 || tile_rank >= tile_ranks || (int64_t)width * height > (1ll << 31) / (aa_x * aa_y)) {
+		rt::set_error("rt_render_submit: bad argument");
+		return RT_EINVAL;
+	}
+	*ticket = 0;
+	HIPCHK(hipSetDevice(sc->device));
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	// shards: one per lane for a frame-sized job; one when per-kernel timings or counters are asked for (they are only
+	// meaningful for kernels running alone) or when the job is small
+	const bool exclusive = (flags & (RT_FLAG_COUNTERS | RT_FLAG_TIME_KERNELS)) != 0;
+	const int64_t tiles = localTiles(width, height, tile_rank, tile_ranks);
+	int nShards = (int)sc->lanes.size();
+	if (exclusive || tiles < 64 * nShards) nShards = 1;
+
+	std::unique_lock<std::mutex> g(sc->mtx);
+	rt_scene::Job* job = &sc->jobs[sc->nextId % RT_MAX_INFLIGHT];
+	if (job->id != 0) { rt::set_error("rt_render_submit: too many frames in flight (wait for an earlier ticket first)"); return RT_EINVAL; }
+	// Shards of consecutive frames may overlap only if they own the same pixels of the shared accumulators
+	bool compatible = !exclusive && sc->accum.npix >= (uint32_t)(width * height) && sc->accum.rgb;
+	for (const rt_scene::Job& j : sc->jobs)
+		if (j.id && j.remaining > 0 &&
+		    (j.W != width || j.H != height || j.tileRank != tile_rank || j.tileRanks != tile_ranks || j.nShards != nShards || (j.flags & (RT_FLAG_COUNTERS | RT_FLAG_TIME_KERNELS))))
+			compatible = false;
+	if (!compatible) sc->drainLocked(g);
+	if (int rc = sc->ensureAccum((uint32_t)(width * height))) return rc;
+	job->cam = *camera; job->W = width; job->H = height; job->aaX = aa_x; job->aaY = aa_y; job->maxDepth = max_depth;
+	job->tileRank = tile_rank; job->tileRanks = tile_ranks; job->nShards = nShards; job->seed = seed; job->flags = flags; job->rgb = rgb_dev; job->st = st;
+	HIPCHK(hipEventRecord(job->evStart, st));   // the lanes start after whatever the caller queued on its stream before this call
+	job->id = sc->nextId++;
+	job->remaining = (int)sc->lanes.size();
+	for (size_t k = 0; k < sc->lanes.size(); k++) { job->rc[k] = RT_OK; job->err[k].clear(); job->part[k] = rt_stats{}; sc->laneQueue[k].push_back(job); }
+	*ticket = job->id;
+	g.unlock();
+	sc->cvWork.notify_all();
+	return RT_OK;
+}
+
+int rt_render_wait(rt_scene* sc, uint64_t ticket, rt_stats* stats) {
+	if (!sc || ticket == 0) { rt::set_error("rt_render_wait: bad argument"); return RT_EINVAL; }
+	HIPCHK(hipSetDevice(sc->device));
+	rt_scene::Job* job = &sc->jobs[ticket % RT_MAX_INFLIGHT];
+	{
+		std::unique_lock<std::mutex> g(sc->mtx);
+		if (job->id != ticket) { rt::set_error("rt_render_wait: unknown ticket"); return RT_EINVAL; }
+		sc->cvDone.wait(g, [&] { return job->remaining == 0; });
+	}
+	auto retire = [&] { std::lock_guard<std::mutex> g(sc->mtx); job->id = 0; };
+	for (int k = 0; k < job->nShards; k++)
+		if (job->rc[k]) {
+			const int rc = job->rc[k];
+			rt::set_error(job->err[k]);
+			for (auto& ln : sc->lanes) (void)hipStreamSynchronize(ln.stream);
+			retire();
+			return rc;
+		}
+	hipError_t e = hipSuccess;
+	for (int k = 0; k < job->nShards && e == hipSuccess; k++) e = hipStreamWaitEvent(job->st, job->evDone[k], 0);
+	if (e == hipSuccess) e = hipEventRecord(job->evEnd, job->st);
+	if (e == hipSuccess) e = hipStreamSynchronize(job->st);
+	rt_stats total{};
+	if (e == hipSuccess) e = hipEventElapsedTime(&total.gpu_ms, job->evStart, job->evEnd);
+	for (int k = 0; k < job->nShards; k++) {
+		const rt_stats& p = job->part[k];
+		total.rays_nearest += p.rays_nearest; total.rays_shadow += p.rays_shadow; total.batch_splits += p.batch_splits;
+		total.nodes_nearest += p.nodes_nearest; total.prims_nearest += p.prims_nearest; total.nodes_shadow += p.nodes_shadow; total.prims_shadow += p.prims_shadow;
+		total.nearest_ms += p.nearest_ms; total.shadow_ms += p.shadow_ms;
+		total.levels = std::max(total.levels, p.levels); total.max_walk = std::max(total.max_walk, p.max_walk);
+	}
+	retire();
+	if (e != hipSuccess) { rt::set_error(std::string("rt_render_wait: ") + hipGetErrorString(e)); return RT_EHIP; }
+	if (stats) *stats = total;
+	return RT_OK;
 }
 
 int rt_render(rt_scene* sc, const rt_camera* camera, int width, int height, int aa_x, int aa_y, int max_depth, int tile_rank, int tile_ranks,
               uint32_t seed, uint32_t flags, float* rgb_dev, void* stream, rt_stats* stats) {
-	if (!sc || !camera || !rgb_dev || width <= 0 || height <= 0 || aa_x < 1 || aa_x > 16 || aa_y < 1 || aa_y > 16 || max_depth < 0 || max_depth > 30 ||
-	    tile_ranks < 1 || tile_rank < 0 || tile_rank >= tile_ranks || (int64_t)width * height > (1ll << 31) / (aa_x * aa_y)) {
-		rt::set_error("rt_render: bad argument");
-		return RT_EINVAL;
-	}
-	hipStream_t st = static_cast<hipStream_t>(stream);
-	if (int rc = begin(sc, st, flags)) return rc;
-	if (int rc = sc->ensureAccum((uint32_t)(width * height))) return rc;
-	Run run{ sc, st, {}, max_depth, seed, flags, (uint32_t)(aa_x * aa_y) };
-	run.src.camera = true; run.src.cam = *camera; run.src.W = width; run.src.H = height; run.src.aaX = aa_x; run.src.aaY = aa_y;
-	run.src.tileRank = tile_rank; run.src.tileRanks = tile_ranks;
-	const uint64_t localPix = (uint64_t)localTiles(width, height, tile_rank, tile_ranks) * 256;
-	if (int rc = run.all(localPix * run.aaSq)) return rc;
-	rtk_resolve(st, sc->accum, width, height, tile_rank, tile_ranks, 0, (uint32_t)localPix, run.aaSq, 0, rgb_dev);
-	// the padding slots of partial edge tiles went through the first level as inactive lanes: they are not rays
-	run.stats.rays_nearest -= (localPix - (uint64_t)ownedPixels(width, height, tile_rank, tile_ranks)) * run.aaSq;
-	return finish(sc, st, run, stats);
+	uint64_t ticket = 0;
+	if (int rc = rt_render_submit(sc, camera, width, height, aa_x, aa_y, max_depth, tile_rank, tile_ranks, seed, flags, rgb_dev, stream, &ticket)) return rc;
+	return rt_render_wait(sc, ticket, stats);
 }
 
 int rt_render_host(rt_scene* sc, const rt_camera* camera, int width, int height, int aa_x, int aa_y, int max_depth, uint32_t seed, uint32_t flags,
@@ -475,6 +671,7 @@ int rt_trace_batch(rt_scene* sc, const float* e, const float* s, size_t n, int m
 	if (!sc || !e || !s || max_depth < 0 || max_depth > 30 || n > (1ull << 31)) { rt::set_error("rt_trace_batch: bad argument"); return RT_EINVAL; }
 	if (stats) memset(stats, 0, sizeof *stats);
 	if (n == 0) return RT_OK;
+	sc->drain();   // the lanes' queues are used directly below
 	HIPCHK(hipSetDevice(sc->device));
 	DevBuf de, ds, dhit, did, dt, drgb;
 	if (int rc = de.alloc(n * 12)) return rc;
@@ -486,14 +683,15 @@ int rt_trace_batch(rt_scene* sc, const float* e, const float* s, size_t n, int m
 	HIPCHK(hipMemcpy(de.p, e, n * 12, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(ds.p, s, n * 12, hipMemcpyHostToDevice));
 	hipStream_t st = nullptr;
-	if (int rc = begin(sc, st, flags)) return rc;
+	rt_scene::Lane* ln = &sc->lanes[0];
+	if (int rc = begin(sc, ln, st, flags)) return rc;
 	if (int rc = sc->ensureAccum((uint32_t)n)) return rc;
-	Run run{ sc, st, {}, max_depth, seed, flags, 1u };
+	Run run{ sc, ln, st, {}, max_depth, seed, flags, 1u };
 	run.src.a = de.as<float>(); run.src.b = ds.as<float>();
 	run.src.outHit = dhit.as<uint8_t>(); run.src.outId = did.as<int32_t>(); run.src.outT = dt.as<float>();
 	if (int rc = run.all(n)) return rc;
 	rtk_resolve(st, sc->accum, 0, 0, 0, 1, 0, (uint32_t)n, 1, 1, drgb.as<float>());
-	if (int rc = finish(sc, st, run, stats)) return rc;
+	if (int rc = finish(sc, ln, st, run, stats)) return rc;
 	if (hit) HIPCHK(hipMemcpy(hit, dhit.p, n, hipMemcpyDeviceToHost));
 	if (obj_id) HIPCHK(hipMemcpy(obj_id, did.p, n * 4, hipMemcpyDeviceToHost));
 	if (t) HIPCHK(hipMemcpy(t, dt.p, n * 4, hipMemcpyDeviceToHost));
@@ -505,6 +703,7 @@ int rt_intersect_batch(rt_scene* sc, const float* e, const float* d, size_t n, u
 	if (!sc || !e || !d || n > (1ull << 31)) { rt::set_error("rt_intersect_batch: bad argument"); return RT_EINVAL; }
 	if (stats) memset(stats, 0, sizeof *stats);
 	if (n == 0) return RT_OK;
+	sc->drain();   // the lanes' queues are used directly below
 	HIPCHK(hipSetDevice(sc->device));
 	DevBuf de, dd, dhit, did, dt;
 	if (int rc = de.alloc(n * 12)) return rc;
@@ -515,18 +714,19 @@ int rt_intersect_batch(rt_scene* sc, const float* e, const float* d, size_t n, u
 	HIPCHK(hipMemcpy(de.p, e, n * 12, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(dd.p, d, n * 12, hipMemcpyHostToDevice));
 	hipStream_t st = nullptr;
-	if (int rc = begin(sc, st, flags)) return rc;
-	Run run{ sc, st, {}, 0, 0, flags, 1u };
+	rt_scene::Lane* ln = &sc->lanes[0];
+	if (int rc = begin(sc, ln, st, flags)) return rc;
+	Run run{ sc, ln, st, {}, 0, 0, flags, 1u };
 	for (size_t c0 = 0; c0 < n; c0 += sc->qcap) {
 		const uint32_t cnt = (uint32_t)std::min<size_t>(sc->qcap, n - c0);
-		HIPCHK(hipMemsetAsync(sc->ctr, 0, RT_COUNTER_RESET_BYTES, st));
-		rtk_load_rays(st, de.as<float>() + 3 * c0, dd.as<float>() + 3 * c0, cnt, 0, sc->ray[0], 0);
-		rtk_intersect(st, sc->dev, sc->hasCsg, (flags & RT_FLAG_COUNTERS) != 0, false, sc->maxBlocks, sc->ray[0], cnt, sc->hitq, sc->ctr);
-		rtk_export_hits(st, sc->dev, sc->hitq, cnt, dhit.as<uint8_t>() + c0, did.as<int32_t>() + c0, dt.as<float>() + c0);
+		HIPCHK(hipMemsetAsync(ln->ctr, 0, RT_COUNTER_RESET_BYTES, st));
+		rtk_load_rays(st, de.as<float>() + 3 * c0, dd.as<float>() + 3 * c0, cnt, 0, ln->ray[0], 0);
+		rtk_intersect(st, sc->dev, sc->hasCsg, (flags & RT_FLAG_COUNTERS) != 0, false, sc->maxBlocks, ln->ray[0], cnt, ln->hitq, ln->ctr);
+		rtk_export_hits(st, sc->dev, ln->hitq, cnt, dhit.as<uint8_t>() + c0, did.as<int32_t>() + c0, dt.as<float>() + c0);
 		run.stats.rays_nearest += cnt;
 	}
 	run.stats.levels = 1;
-	if (int rc = finish(sc, st, run, stats)) return rc;
+	if (int rc = finish(sc, ln, st, run, stats)) return rc;
 	if (hit) HIPCHK(hipMemcpy(hit, dhit.p, n, hipMemcpyDeviceToHost));
 	if (obj_id) HIPCHK(hipMemcpy(obj_id, did.p, n * 4, hipMemcpyDeviceToHost));
 	if (t) HIPCHK(hipMemcpy(t, dt.p, n * 4, hipMemcpyDeviceToHost));
@@ -537,6 +737,7 @@ int rt_shadow_batch(rt_scene* sc, const float* point, const float* light_pos, si
 	if (!sc || !point || !light_pos || n > (1ull << 31)) { rt::set_error("rt_shadow_batch: bad argument"); return RT_EINVAL; }
 	if (stats) memset(stats, 0, sizeof *stats);
 	if (n == 0) return RT_OK;
+	sc->drain();   // the lanes' queues are used directly below
 	HIPCHK(hipSetDevice(sc->device));
 	DevBuf dp, dl, dlit, dsh;
 	if (int rc = dp.alloc(n * 12)) return rc;
@@ -546,11 +747,12 @@ int rt_shadow_batch(rt_scene* sc, const float* point, const float* light_pos, si
 	HIPCHK(hipMemcpy(dp.p, point, n * 12, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(dl.p, light_pos, n * 12, hipMemcpyHostToDevice));
 	hipStream_t st = nullptr;
-	if (int rc = begin(sc, st, flags)) return rc;
-	Run run{ sc, st, {}, 0, 0, flags & ~RT_FLAG_COUNTERS, 1u };
+	rt_scene::Lane* ln = &sc->lanes[0];
+	if (int rc = begin(sc, ln, st, flags)) return rc;
+	Run run{ sc, ln, st, {}, 0, 0, flags & ~RT_FLAG_COUNTERS, 1u };
 	rtk_shadow_query(st, sc->dev, sc->hasCsg, dp.as<float>(), dl.as<float>(), (uint32_t)n, dlit.as<uint8_t>(), dsh.as<float>());
 	run.stats.rays_shadow = n;
-	if (int rc = finish(sc, st, run, stats)) return rc;
+	if (int rc = finish(sc, ln, st, run, stats)) return rc;
 	if (lit) HIPCHK(hipMemcpy(lit, dlit.p, n, hipMemcpyDeviceToHost));
 	if (shadow) HIPCHK(hipMemcpy(shadow, dsh.p, n * 12, hipMemcpyDeviceToHost));
 	return RT_OK;

@@ -12,6 +12,9 @@
 #ifndef RT_REFILL_BELOW
 #define RT_REFILL_BELOW 48
 #endif
+#ifndef RT_PACKET_WAVES_PER_SIMD
+#define RT_PACKET_WAVES_PER_SIMD 5   /* register budget of the packet kernels: 512 / 5 -> 96 VGPRs (6 and 8 spill and are slower) */
+#endif
 #define RT_STACK_DEPTH 20     /* per-lane traversal stack entries in LDS (20 x 256 x 4 B = 20 KB per workgroup);
                                  a nearer-child-first walk of a binary tree needs at most its depth, and the
                                  reference's build stops at depth 16 (bvh.h:6); checked at upload */
@@ -64,6 +67,7 @@ struct RtCounters {
 	unsigned long long nodes_shadow, prims_shadow;     // ... and in the shadow kernels
 #if RT_PROF
 	unsigned long long trace[2][4][RT_TRACE_LEN];      // RT_PROF builds: step traces of four waves of the two packet kernels
+	uint32_t waveLog[2][8192][8];                      // per wave: start, end (100 MHz wall clock), longest packet, packets; that packet's union steps, max / sum of per-ray nodes, rays
 #endif
 };
 

@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 using namespace rtd;
 
@@ -189,6 +191,9 @@ struct Trav {
 	float tmin; uint32_t best, bestKey, bestTag;   // nearest
 	f3 shadow; float len; bool lit;                 // any-hit
 	unsigned long long cntNodes, cntPrims;
+#if RT_PROF
+	uint32_t steps;
+#endif
 };
 
 template <bool ANYHIT>
@@ -198,6 +203,9 @@ __device__ __forceinline__ void travInit(const DevScene& S, Trav& T, f3 e, f3 d)
 	T.special = !(fabsf(T.inv.x) <= 3.0e38f && fabsf(T.inv.y) <= 3.0e38f && fabsf(T.inv.z) <= 3.0e38f);
 	T.sp = 0; T.cur = kEmpty;
 	T.cntNodes = 0; T.cntPrims = 0;
+#if RT_PROF
+	T.steps = 0;
+#endif
 	T.tmin = RT_MAX_T; T.best = RT_NO_HIT; T.bestKey = 0; T.bestTag = 0;   // bvh.cpp:73
 	T.shadow = mk3(1.0f, 1.0f, 1.0f); T.lit = true; T.len = 0;
 	if (!ANYHIT) {
@@ -353,13 +361,22 @@ __device__ __forceinline__ Tracer tracerFor(RtCounters* ctr, int kernel) {
 	tr.on = slot >= 0; tr.n = 0; tr.buf = ctr->trace[kernel][slot < 0 ? 0 : slot];
 	return tr;
 }
-#define TR_DECL(kernel) Tracer tr = tracerFor(ctr, kernel); Tracer* trp = &tr;
+#define TR_DECL(kernel) Tracer tr = tracerFor(ctr, kernel); Tracer* trp = &tr; \
+	const uint32_t wlK = kernel; const uint32_t wlStart = (uint32_t)wall_clock64(); uint32_t wlLast = wlStart, wlMax = 0, wlN = 0, wlSteps = 0, wlLaneMax = 0, wlLaneSum = 0, wlLanes = 0;
+#define WL_PACKET(T, alive) do { const uint32_t _n = (uint32_t)wall_clock64(); if (_n - wlLast > wlMax) { wlMax = _n - wlLast; \
+		uint32_t _c = (alive) ? (uint32_t)(T).cntNodes : 0u, _m = _c, _s = _c; \
+		for (int _o = 32; _o; _o >>= 1) { const uint32_t _a = __shfl_xor(_m, _o), _b = __shfl_xor(_s, _o); _m = _a > _m ? _a : _m; _s += _b; } \
+		wlSteps = __builtin_amdgcn_readfirstlane((T).steps); wlLaneMax = _m; wlLaneSum = _s; wlLanes = (uint32_t)__popcll(__ballot(alive)); } wlLast = _n; wlN++; } while (0)
+#define WL_END() do { if (__lane_id() == 0 && waveNumber() < 8192u) { uint32_t* _w = ctr->waveLog[wlK][waveNumber()]; _w[0] = wlStart; _w[1] = (uint32_t)wall_clock64(); _w[2] = wlMax; _w[3] = wlN; \
+		_w[4] = wlSteps; _w[5] = wlLaneMax; _w[6] = wlLaneSum; _w[7] = wlLanes; } } while (0)
 #define TR(tag, val) do { if (trp->on) { const unsigned long long _t = __builtin_readcyclecounter(); \
 	if (__lane_id() == 0 && trp->n < RT_TRACE_LEN) trp->buf[trp->n] = ((unsigned long long)(tag) << 56) | ((unsigned long long)((val) & 0xffffu) << 40) | (_t & 0xffffffffffull); trp->n++; } } while (0)
 #define TR_ARG , trp
 #else
 struct Tracer;
 #define TR_DECL(kernel)
+#define WL_PACKET(T, alive) do { } while (0)
+#define WL_END() do { } while (0)
 #define TR(tag, val) do { } while (0)
 #define TR_ARG
 #endif
@@ -428,12 +445,19 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 	int32_t node = S.treelet_root;
 	uint32_t info = node < 0 ? S.treelet_root_aux : 0u;   // inner node: treelet level; leaf: aux
 	int sp = 0;
+	// (Measured and dropped: raising the wave's issue priority with the length of its walk, and prefetching a pushed
+	// treelet with an asynchronous global->LDS copy into a scratch buffer -- neither moved the launch time: the long
+	// walks that end a launch are bound by their own chain of dependent steps.  Their tails are instead filled with
+	// other shards of the frame, see rt_capi_device.hip.)
 	for (;;) {
 		node = __builtin_amdgcn_readfirstlane(node);
 		info = __builtin_amdgcn_readfirstlane(info);
 		bool popNext = true;
 		if (node >= 0) {
 			TR(3, node & 15);
+#if RT_PROF
+			T.steps++;
+#endif
 			float4* buf = L.level(info);
 			if ((node & (RT_TREELET_SLOTS - 1)) == 0 && node != 0) {   // the root of a deeper treelet: stage it
 				buf[lane] = S.treelets[(size_t)node * 4 + lane];
@@ -448,7 +472,7 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			int k0 = 0, k1 = 0;
 			float t0 = 0, t1 = 0;
 			if (inSub) {
-				if (COUNT) T.cntNodes++;
+				if (COUNT || RT_PROF) T.cntNodes++;
 				const float tlimit = ANYHIT ? 1.0f : T.tmin;
 				k0 = boxClassify(b0, T.e, T.inv, T.special, tlimit, t0);
 				k1 = boxClassify(b1, T.e, T.inv, T.special, tlimit, t1);
@@ -656,7 +680,7 @@ __device__ __forceinline__ uint32_t fetchPacket(uint32_t* head, uint32_t nPacket
 
 // Nearest hit for coherent ray sets: one packet = 64 consecutive queue slots (an 8x8 pixel block of the tile order).
 template <bool CSG, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_intersect_packet(DevScene S, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr, uint32_t groupStride) {
+__global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_intersect_packet(DevScene S, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr, uint32_t groupStride) {
 	const uint32_t lane = __lane_id();
 	const PacketLds ws = packetLdsInit(S);
 	// Hand-out order: groups of kPacketGroup neighbouring packets, the groups visited with a stride coprime to their
@@ -706,7 +730,9 @@ __global__ __launch_bounds__(kBlock) void k_intersect_packet(DevScene S, RtQueue
 		}
 		if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
 		TR(11, 0);
+		WL_PACKET(T, cur.alive);
 	}
+	WL_END();
 	if (COUNT) { atomicAdd(&ctr->nodes_nearest, cn); atomicAdd(&ctr->prims_nearest, cp); }
 }
 
@@ -982,7 +1008,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq,
 // Packet form of k_shadow_point for coherent surface sets: 64 consecutive surfaces towards the same light.  Only the
 // surface point is held during the walk; the rest of the surface record is read when the ray turned out lit.
 template <bool CSG, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_shadow_point_packet(DevScene S, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
+__global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_shadow_point_packet(DevScene S, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                                                                 RtAccum A, uint32_t aaSq, RtCounters* ctr) {
 	const uint32_t lane = __lane_id();
 	const PacketLds ws = packetLdsInit(S);
@@ -1031,7 +1057,9 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point_packet(DevScene S, RtQu
 			}
 		}
 		TR(11, 0);
+		WL_PACKET(T, alive);
 	}
+	WL_END();
 	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
 }
 
@@ -1153,15 +1181,25 @@ inline unsigned gridPersistent(unsigned long long n, int maxBlocks) { return (un
 // Persistent kernels start every wave on a statically numbered piece of work, so the grid must not exceed what is
 // resident at once (a workgroup that only starts when another has finished would sit on its piece until the end).
 static int computeUnits() {
-	static int cus = 0;
-	if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+	static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
 	return cus;
 }
+// resident workgroups per CU of `kernel` with `lds` bytes of dynamic LDS (cached; launches come from several host threads)
+template <class K> static int residentPerCU(K kernel, const char* name, size_t lds) {
+	struct Entry { const void* k; size_t lds; int perCU; };
+	static std::mutex m;
+	static std::vector<Entry> cache;
+	std::lock_guard<std::mutex> g(m);
+	for (const Entry& e : cache) if (e.k == (const void*)kernel && e.lds == lds) return e.perCU;
+	int perCU = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlock, lds) != hipSuccess || perCU <= 0) perCU = 1;
+	if (getenv("RT_DEBUG_GRID")) fprintf(stderr, "[grid] %s: %d workgroups/CU resident with %zu B LDS\n", name, perCU, lds);
+	cache.push_back({ (const void*)kernel, lds, perCU });
+	return perCU;
+}
 #define RT_LAUNCH_PS(kernel, n, maxBlocks, lds, stream, ...) do { if ((n) > 0) { \
-		static int _perCU = 0; static size_t _lds = ~(size_t)0; \
-		if (_lds != (size_t)(lds)) { _lds = (size_t)(lds); if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&_perCU, kernel, kBlock, _lds) != hipSuccess || _perCU <= 0) _perCU = 1; \
-			if (getenv("RT_DEBUG_GRID")) fprintf(stderr, "[grid] %s: %d workgroups/CU resident with %zu B LDS\n", #kernel, _perCU, _lds); } \
-		hipLaunchKernelGGL(kernel, dim3(gridPersistent(n, std::min(maxBlocks, _perCU * computeUnits()))), dim3(kBlock), _lds, stream, __VA_ARGS__); } } while (0)
+		const int _perCU = residentPerCU(kernel, #kernel, (size_t)(lds)); \
+		hipLaunchKernelGGL(kernel, dim3(gridPersistent(n, std::min(maxBlocks, _perCU * computeUnits()))), dim3(kBlock), (size_t)(lds), stream, __VA_ARGS__); } } while (0)
 #define RT_LAUNCH_P(kernel, n, maxBlocks, stream, ...) RT_LAUNCH_PS(kernel, n, maxBlocks, 0, stream, __VA_ARGS__)
 #define RT_LAUNCH_S(kernel, n, lds, stream, ...) do { if ((n) > 0) hipLaunchKernelGGL(kernel, dim3(gridFor(n)), dim3(kBlock), lds, stream, __VA_ARGS__); } while (0)
 static size_t packetLdsBytes(const DevScene& S) { return (size_t)RT_PACKET_LDS_BYTES(S.treelet_levels, S.treelet_staging); }

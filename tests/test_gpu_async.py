@@ -1,0 +1,81 @@
+"""GPU suite, part 3: frames in flight (rt_render_submit / rt_render_wait) give exactly the frames of the synchronous call,
+whatever the camera changes between them, and the ticket rules are enforced."""
+import numpy as np
+import pytest
+import torch
+
+import raytracer_amd as rt
+from raytracer_amd import scenes
+from raytracer_amd.capi import RtError
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c2(tmp_path_factory):
+    flat = rt.FlatScene.from_json(scenes.c2_scene(str(tmp_path_factory.mktemp("c2async"), ), grid=96))
+    sc = rt.Scene(flat, 0)
+    yield flat, sc
+    sc.close()
+
+
+def test_frames_in_flight_equal_synchronous_frames(c2):
+    flat, sc = c2
+    W, H = 960, 540
+    cams = [rt.Camera(flat.fov, W, H, eye=(0.1 * i, 1.5, 1.0 - 0.2 * i), rot_x=-0.3, rot_y=0.05 * i) for i in range(6)]
+    ref = []
+    buf = torch.zeros(H, W, 3, device="cuda")
+    for cam in cams:
+        sc.render_into(buf.data_ptr(), W, H, camera=cam)
+        ref.append(buf.cpu().numpy().copy())
+    bufs = [torch.zeros(H, W, 3, device="cuda") for _ in range(3)]
+    pending, got, rays = [], [], []
+    for i, cam in enumerate(cams):
+        if len(pending) == 3:
+            t, b = pending.pop(0)
+            rays.append(sc.render_wait(t)["rays_nearest"])
+            got.append(b.cpu().numpy().copy())
+        b = bufs[i % 3]
+        pending.append((sc.render_submit(b.data_ptr(), W, H, camera=cam), b))
+    for t, b in pending:
+        rays.append(sc.render_wait(t)["rays_nearest"])
+        got.append(b.cpu().numpy().copy())
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+    assert all(n == W * H for n in rays)
+
+
+def test_mixed_sizes_and_other_entry_points_between_frames(c2):
+    flat, sc = c2
+    a, b = torch.zeros(270, 480, 3, device="cuda"), torch.zeros(540, 960, 3, device="cuda")
+    cam_a, cam_b = rt.Camera(flat.fov, 480, 270, eye=(0, 1.5, 1.0), rot_x=-0.3), rt.Camera(flat.fov, 960, 540, eye=(0, 1.5, 1.0), rot_x=-0.3)
+    ta = sc.render_submit(a.data_ptr(), 480, 270, camera=cam_a)
+    tb = sc.render_submit(b.data_ptr(), 960, 540, camera=cam_b)          # another size: the lanes run dry first
+    e = np.zeros((64, 3), np.float32) + np.array([0, 1.5, 1.0], np.float32)
+    s = e + np.array([0, -0.3, -1.0], np.float32)
+    hits = sc.trace_batch(e, s)                                           # waits for the frames in flight
+    sc.render_wait(tb)
+    sc.render_wait(ta)
+    ra, rb = torch.zeros_like(a), torch.zeros_like(b)
+    sc.render_into(ra.data_ptr(), 480, 270, camera=cam_a)
+    sc.render_into(rb.data_ptr(), 960, 540, camera=cam_b)
+    assert torch.equal(a, ra) and torch.equal(b, rb)
+    assert hits["hit"].all()
+
+
+def test_ticket_rules(c2):
+    flat, sc = c2
+    W, H = 480, 270
+    cam = rt.Camera(flat.fov, W, H, eye=(0, 1.5, 1.0), rot_x=-0.3)
+    bufs = [torch.zeros(H, W, 3, device="cuda") for _ in range(5)]
+    tickets = [sc.render_submit(bufs[i].data_ptr(), W, H, camera=cam) for i in range(4)]
+    with pytest.raises(RtError):
+        sc.render_submit(bufs[4].data_ptr(), W, H, camera=cam)            # a fifth frame in flight
+    for t in tickets:
+        sc.render_wait(t)
+    with pytest.raises(RtError):
+        sc.render_wait(tickets[0])                                        # waited for already
+    with pytest.raises(RtError):
+        sc.render_wait(12345)
+    assert all(torch.equal(bufs[0], b) for b in bufs[1:4])

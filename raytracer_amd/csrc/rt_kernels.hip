@@ -166,6 +166,22 @@ __device__ __forceinline__ int boxClassify(const float* b, const f3& e, const f3
 	return 2;                               // too close to call (or not a number): the reference's own arithmetic decides
 }
 
+// The same test without control flow, for the packet walk (every instruction of a step is paid by the whole wave, and
+// branches around a few instructions cost more than they save): `hit` = certainly visit, `amb` = the exact test
+// decides.  Lanes of `special` rays are made ambiguous by the caller.
+__device__ __forceinline__ void boxClassifyFlat(const float* b, const f3& e, const f3& inv, float tlimit, float& tEntry, bool& hit, bool& amb) {
+	const v2f_ bx = { b[0], b[1] }, by = { b[2], b[3] }, bz = { b[4], b[5] };
+	const v2f_ tx = (bx - e.x) * inv.x, ty = (by - e.y) * inv.y, tz = (bz - e.z) * inv.z;
+	const float lo = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), -RT_MAX_T));
+	const float hi = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), RT_MAX_T));
+	tEntry = lo;
+	const float u = fminf(hi, tlimit);
+	const float g = u - lo;
+	const float m = 1e-6f * (fabsf(lo) + fabsf(u)) + 1e-30f;
+	hit = g > m && hi > 1e-30f;
+	amb = !(hit || g < -m || hi < -1e-30f);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Per-lane traversal state for both queries:
 //   nearest  BVH::findNearest (bvh.cpp:72-92) + findRecursive (bvh.cpp:94-121)
@@ -468,38 +484,40 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			const float4 a = q[0], b = q[1], c = q[2], d = q[3];
 			const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
 			const float b1[6] = { b.z, b.w, c.x, c.y, c.z, c.w };
-			const int32_t c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
-			int k0 = 0, k1 = 0;
-			float t0 = 0, t1 = 0;
-			if (inSub) {
-				if (COUNT || RT_PROF) T.cntNodes++;
-				const float tlimit = ANYHIT ? 1.0f : T.tmin;
-				k0 = boxClassify(b0, T.e, T.inv, T.special, tlimit, t0);
-				k1 = boxClassify(b1, T.e, T.inv, T.special, tlimit, t1);
-				if (k0 == 2) { const float t = boxIntersect(b0, T.e, T.d, false); k0 = !(t < 0 || t > tlimit); }
-				if (k1 == 2) { const float t = boxIntersect(b1, T.e, T.d, false); k1 = !(t < 0 || t > tlimit); }
+			// the references are the same in every lane: keep them in scalar registers
+			const int32_t c0 = __builtin_amdgcn_readfirstlane(__float_as_int(d.x)), c1 = __builtin_amdgcn_readfirstlane(__float_as_int(d.y));
+			const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(d.z)), x1 = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(d.w));
+			TR(12, 0);
+			const float tlimit = ANYHIT ? 1.0f : T.tmin;
+			float t0, t1;
+			bool h0, h1, a0, a1;
+			boxClassifyFlat(b0, T.e, T.inv, tlimit, t0, h0, a0);
+			boxClassifyFlat(b1, T.e, T.inv, tlimit, t1, h1, a1);
+			h0 = h0 && inSub && !T.special; h1 = h1 && inSub && !T.special;
+			a0 = (a0 || T.special) && inSub; a1 = (a1 || T.special) && inSub;
+			if (COUNT || RT_PROF) T.cntNodes += inSub ? 1u : 0u;
+			if (__ballot(a0 || a1) != 0) {   // too close to call somewhere in the wave (rare): the reference's own arithmetic decides
+				if (a0) { const float t = boxIntersect(b0, T.e, T.d, false); h0 = !(t < 0 || t > tlimit); }
+				if (a1) { const float t = boxIntersect(b1, T.e, T.d, false); h1 = !(t < 0 || t > tlimit); }
 			}
-			const unsigned long long m0 = __ballot(k0 != 0), m1 = __ballot(k1 != 0);
+			const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
 			TR(5, __popcll(m0 | m1));
 			// what travels with a child: its treelet level (one more when it roots another treelet) or its leaf aux word
-			const uint32_t i0 = c0 < 0 ? __float_as_uint(d.z) : info + (((c0 ^ node) >> 4) != 0);
-			const uint32_t i1 = c1 < 0 ? __float_as_uint(d.w) : info + (((c1 ^ node) >> 4) != 0);
+			const uint32_t i0 = c0 < 0 ? x0 : info + (((c0 ^ node) >> 4) != 0);
+			const uint32_t i1 = c1 < 0 ? x1 : info + (((c1 ^ node) >> 4) != 0);
 			if (m0 != 0 && m1 != 0) {
 				// visit first the child most rays reach first (any order is correct; ties go to the reference's order by key)
-				const unsigned long long both = m0 & m1;
-				const bool swap = !ANYHIT && 2 * __popcll(__ballot(k0 && k1 && t1 < t0)) > __popcll(both);
+				const bool swap = 2 * __popcll(__ballot(h0 && h1 && t1 < t0)) > __popcll(m0 & m1);
 				const unsigned long long mFar = swap ? m0 : m1;
 				if (sp < kStack) {
-					L.stack[sp][0] = (uint32_t)(swap ? c0 : c1);
-					L.stack[sp][1] = (uint32_t)mFar; L.stack[sp][2] = (uint32_t)(mFar >> 32);
-					L.stack[sp][3] = swap ? i0 : i1;
+					*reinterpret_cast<uint4*>(L.stack[sp]) = make_uint4((uint32_t)(swap ? c0 : c1), (uint32_t)mFar, (uint32_t)(mFar >> 32), swap ? i0 : i1);
 					sp++;
 				}
 				node = swap ? c1 : c0; info = swap ? i1 : i0;
-				inSub = swap ? k1 != 0 : k0 != 0;
+				inSub = swap ? h1 : h0;
 				popNext = false;
-			} else if (m0 != 0) { node = c0; info = i0; inSub = k0 != 0; popNext = false; }
-			else if (m1 != 0) { node = c1; info = i1; inSub = k1 != 0; popNext = false; }
+			} else if (m0 != 0) { node = c0; info = i0; inSub = h0; popNext = false; }
+			else if (m1 != 0) { node = c1; info = i1; inSub = h1; popNext = false; }
 			TR(6, sp);
 		} else if (info != RT_TREELET_NO_RUN) {   // leaf made of consecutive triangles: no leaf_prims indirection
 			const uint32_t count = info >> 26;
@@ -539,9 +557,10 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			for (;;) {
 				if (sp == 0) return;
 				sp--;
-				const unsigned long long m = (unsigned long long)L.stack[sp][1] | ((unsigned long long)L.stack[sp][2] << 32);
-				node = (int32_t)L.stack[sp][0];
-				info = L.stack[sp][3];
+				const uint4 entry = *reinterpret_cast<const uint4*>(L.stack[sp]);
+				const unsigned long long m = (unsigned long long)entry.y | ((unsigned long long)entry.z << 32);
+				node = (int32_t)entry.x;
+				info = entry.w;
 				inSub = ((m >> lane) & 1ull) != 0 && (!ANYHIT || T.lit);
 				if (__ballot(inSub) != 0) break;   // nobody left who wants this subtree (occluded lanes)
 			}
@@ -555,6 +574,10 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 // wave-local pool and refills its idle lanes from the pool.
 constexpr uint32_t kWorkChunk = 128;
 constexpr uint32_t kPacketGroup = 8;
+#ifndef RT_PACKET_CHUNK
+#define RT_PACKET_CHUNK 1
+#endif
+constexpr uint32_t kPacketChunk = RT_PACKET_CHUNK;   // packets per cursor atomic (divides kPacketGroup); 2 and 4 measured slower: the statically handed-out share grows with it and unbalances the launch
 struct WorkPool { uint32_t next, end; bool drained; };
 
 __device__ __forceinline__ uint32_t fetchWork(bool need, WorkPool& pool, uint32_t* head, unsigned long long total) {
@@ -671,11 +694,26 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RtQueue rq, ui
 // back in order it cannot be hidden behind other memory work.)  Measured alternatives, both dropped: cutting the
 // range into eight per-XCD parts so that each L2 sees one band of the image was 1.8x SLOWER on the C2 frame, and
 // handing packets out in a scattered order to avoid neighbouring waves walking the same lines gained only 5 %.
-__device__ __forceinline__ uint32_t fetchPacket(uint32_t* head, uint32_t nPackets) {
-	uint32_t k = 0;
-	if (__lane_id() == 0) k = atomicAdd(head, 1u);
-	k = __builtin_amdgcn_readfirstlane(k) + waveCount();
-	return k < nPackets ? k : kInactive;
+// Packets are handed out kPacketChunk at a time: packet numbers wave*chunk .. +chunk-1 statically, then chunks from
+// the cursor.  PacketFeed walks through the chunk a wave holds.
+struct PacketFeed { uint32_t next, end; };
+__device__ __forceinline__ PacketFeed firstPackets(uint32_t nPackets) {
+	const unsigned long long b = (unsigned long long)waveNumber() * kPacketChunk;
+	PacketFeed f;
+	f.next = (uint32_t)(b < nPackets ? b : nPackets);
+	f.end = (uint32_t)(b + kPacketChunk < nPackets ? b + kPacketChunk : nPackets);
+	return f;
+}
+__device__ __forceinline__ uint32_t fetchPacket(PacketFeed& f, uint32_t* head, uint32_t nPackets) {
+	if (f.next == f.end) {
+		uint32_t k = 0;
+		if (__lane_id() == 0) k = atomicAdd(head, kPacketChunk);
+		const unsigned long long b = (unsigned long long)__builtin_amdgcn_readfirstlane(k) + (unsigned long long)waveCount() * kPacketChunk;
+		if (b >= nPackets) return kInactive;
+		f.next = (uint32_t)b;
+		f.end = (uint32_t)(b + kPacketChunk < nPackets ? b + kPacketChunk : nPackets);
+	}
+	return f.next++;
 }
 
 // Nearest hit for coherent ray sets: one packet = 64 consecutive queue slots (an 8x8 pixel block of the tile order).
@@ -710,7 +748,8 @@ __global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_intersect_
 		}
 		return r;
 	};
-	uint32_t pk = permute(waveNumber() < nPackets ? waveNumber() : kInactive);
+	PacketFeed feed = firstPackets(nPackets);
+	uint32_t pk = permute(feed.next < feed.end ? feed.next++ : kInactive);
 	while (pk != kInactive) {
 		TR(1, pk);
 		const Rays cur = loadRays(pk);
@@ -721,7 +760,7 @@ __global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_intersect_
 		TR(2, __popcll(__ballot(T.cur != kEmpty)));
 		packetTraverse<false, CSG, COUNT>(S, ws, T, cur.alive TR_ARG);
 		TR(9, 0);
-		pk = permute(fetchPacket(&ctr->head_nearest, nPackets));
+		pk = permute(fetchPacket(feed, &ctr->head_nearest, nPackets));
 		TR(10, 0);
 		if (idx < n) {
 			qsu(hq, HQ_PRIM, idx, cur.alive ? T.best : RT_NO_HIT);
@@ -809,18 +848,15 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
                                                   RtAccum A, uint32_t aaSq, int maxDepth, int wantSurfaces,
                                                   uint8_t* outHit, int32_t* outId, float* outT) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	const bool live = i < n && qu(rq, RQ_PIX, i < n ? i : 0) != kInactive;
-	uint32_t pixKey = 0, path = 1, prim = RT_NO_HIT;
-	f3 e = mk3(0, 0, 0), d = mk3(0, 0, 1), w = mk3(0, 0, 0);
-	float t = 0;
-	if (live) {
-		pixKey = qu(rq, RQ_PIX, i); path = qu(rq, RQ_PATH, i);
-		e = mk3(qf(rq, RQ_OX, i), qf(rq, RQ_OY, i), qf(rq, RQ_OZ, i));
-		d = mk3(qf(rq, RQ_DX, i), qf(rq, RQ_DY, i), qf(rq, RQ_DZ, i));
-		w = mk3(qf(rq, RQ_WR, i), qf(rq, RQ_WG, i), qf(rq, RQ_WB, i));
-		prim = qu(hq, HQ_PRIM, i);
-		t = qf(hq, HQ_T, i);
-	}
+	// every record is read at once (index clamped, result masked): one memory round trip instead of two
+	const uint32_t ic = i < n ? i : 0u;
+	uint32_t pixKey = qu(rq, RQ_PIX, ic), path = qu(rq, RQ_PATH, ic), prim = qu(hq, HQ_PRIM, ic);
+	f3 e = mk3(qf(rq, RQ_OX, ic), qf(rq, RQ_OY, ic), qf(rq, RQ_OZ, ic));
+	f3 d = mk3(qf(rq, RQ_DX, ic), qf(rq, RQ_DY, ic), qf(rq, RQ_DZ, ic));
+	f3 w = mk3(qf(rq, RQ_WR, ic), qf(rq, RQ_WG, ic), qf(rq, RQ_WB, ic));
+	float t = qf(hq, HQ_T, ic);
+	const bool live = i < n && pixKey != kInactive;
+	if (!live) { pixKey = 0; path = 1; prim = RT_NO_HIT; e = mk3(0, 0, 0); d = mk3(0, 0, 1); w = mk3(0, 0, 0); t = 0; }
 	const uint32_t pixel = pixKey / aaSq;
 	const bool hit = live && prim != RT_NO_HIT;
 	const f3 background = ld3(S.background);
@@ -899,8 +935,32 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 		wantS = wantSurfaces != 0;
 	}
 
-	// ---- convergent part: wave-compacted appends ----
-	const uint32_t sr = wavePush(wantR, &ctr->next_count);
+	// ---- convergent part: compacted appends, ONE atomic per counter per workgroup.  An append counter is a single
+	// address, and a single address takes ~90 atomics per microsecond on this GPU: with one atomic per wave (32 400 waves
+	// a frame) that rate, not memory or arithmetic, set the time of this kernel. ----
+	uint32_t sr, st, ss;
+	{
+		__shared__ uint32_t waveCount[kBlock / 64][3];
+		__shared__ uint32_t blockBase[2];
+		const unsigned long long mR = __ballot(wantR), mT = __ballot(wantT), mS = __ballot(wantS);
+		const uint32_t lane = __lane_id(), wv = threadIdx.x >> 6;
+		if (lane == 0) { waveCount[wv][0] = (uint32_t)__popcll(mR); waveCount[wv][1] = (uint32_t)__popcll(mT); waveCount[wv][2] = (uint32_t)__popcll(mS); }
+		__syncthreads();
+		uint32_t beforeN = 0, beforeS = 0, totalN = 0, totalS = 0;   // rays / surfaces of the waves before this one, and of the workgroup
+		for (uint32_t k = 0; k < kBlock / 64; k++) {
+			const uint32_t cn = waveCount[k][0] + waveCount[k][1], cs = waveCount[k][2];
+			if (k < wv) { beforeN += cn; beforeS += cs; }
+			totalN += cn; totalS += cs;
+		}
+		if (threadIdx.x == 0 && totalN > 0) blockBase[0] = atomicAdd(&ctr->next_count, totalN);
+		if (threadIdx.x == 64 && totalS > 0) blockBase[1] = atomicAdd(&ctr->surf_count, totalS);
+		__syncthreads();
+		const unsigned long long below = (1ull << lane) - 1ull;
+		const uint32_t baseN = blockBase[0] + beforeN, baseS = blockBase[1] + beforeS;
+		sr = baseN + (uint32_t)__popcll(mR & below);
+		st = baseN + (uint32_t)__popcll(mR) + (uint32_t)__popcll(mT & below);
+		ss = baseS + (uint32_t)__popcll(mS & below);
+	}
 	if (wantR) {
 		if (sr < nq.cap) {
 			qsf(nq, RQ_OX, sr, rO.x); qsf(nq, RQ_OY, sr, rO.y); qsf(nq, RQ_OZ, sr, rO.z);
@@ -909,7 +969,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 			qsu(nq, RQ_PIX, sr, pixKey); qsu(nq, RQ_PATH, sr, path * 2u);
 		} else ctr->overflow = 1;
 	}
-	const uint32_t st = wavePush(wantT, &ctr->next_count);
 	if (wantT) {
 		if (st < nq.cap) {
 			qsf(nq, RQ_OX, st, tO.x); qsf(nq, RQ_OY, st, tO.y); qsf(nq, RQ_OZ, st, tO.z);
@@ -918,7 +977,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 			qsu(nq, RQ_PIX, st, pixKey); qsu(nq, RQ_PATH, st, path * 2u + 1u);
 		} else ctr->overflow = 1;
 	}
-	const uint32_t ss = wavePush(wantS, &ctr->surf_count);
 	if (wantS) {
 		if (ss < sq.cap) {
 			qsf(sq, SQ_PX, ss, p.x); qsf(sq, SQ_PY, ss, p.y); qsf(sq, SQ_PZ, ss, p.z);
@@ -1026,7 +1084,8 @@ __global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_shadow_poi
 		}
 		return p;
 	};
-	uint32_t q = waveNumber() < totalPackets ? waveNumber() : kInactive;
+	PacketFeed feed = firstPackets(totalPackets);
+	uint32_t q = feed.next < feed.end ? feed.next++ : kInactive;
 	while (q != kInactive) {
 		TR(1, q);
 		const f3 p = loadPoint(q);
@@ -1043,7 +1102,7 @@ __global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_shadow_poi
 		TR(2, __popcll(__ballot(T.cur != kEmpty)));
 		packetTraverse<true, CSG, COUNT>(S, ws, T, alive TR_ARG);
 		TR(9, 0);
-		q = fetchPacket(&ctr->head_shadow, totalPackets);
+		q = fetchPacket(feed, &ctr->head_shadow, totalPackets);
 		TR(10, 0);
 		if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
 		if (alive && T.lit) {

@@ -5,11 +5,11 @@ import numpy as np
 
 LEN = 2048
 NAMES = {1: "packet start", 2: "rays+init", 3: "step start", 4: "staged", 5: "classified", 6: "step end", 7: "leaf start", 8: "leaf end",
-         9: "walk done", 10: "fetched", 11: "stored"}
+         9: "walk done", 10: "fetched", 11: "stored", 12: "node read"}
 
 
 def main(path, dump=0):
-    raw = np.fromfile(path, dtype=np.uint64).reshape(2, 4, LEN)
+    raw = np.fromfile(path, dtype=np.uint64)[:2 * 4 * LEN].reshape(2, 4, LEN)
     for k, kname in enumerate(("nearest", "shadow")):
         for w in range(4):
             ev = raw[k, w]

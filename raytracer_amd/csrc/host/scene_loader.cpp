@@ -69,6 +69,48 @@ struct BuildObj {
 	vec3 centroid;
 };
 
+// Triangles of a mesh object: the reference's "triangles" (+ "uvCoords") arrays, or -- additive, SURVEY.md section
+// 8f-2 -- "file": a little-endian binary next to the scene's assets, so that a 5 M-triangle mesh does not have to go
+// through half a gigabyte of JSON text:
+//   char magic[8] = "RTMESH01"; uint64 triangles; uint32 has_uv; uint32 reserved;
+//   float xyz[triangles][3][3];  float uv[triangles][3][2] (if has_uv)
+struct MeshData {
+	const Value* tj = nullptr;
+	const Value* uvj = nullptr;
+	std::vector<float> pos, uv;
+	size_t count = 0;
+	bool hasUv = false;
+
+	void load(const Value& object, const std::string& assetDir) {
+		if (object.has("file")) {
+			const std::string path = assetDir + object["file"].string();
+			FILE* f = fopen(path.c_str(), "rb");
+			if (!f) throw std::runtime_error("mesh file not found: " + path);
+			char magic[8]; uint64_t n = 0; uint32_t flags[2] = { 0, 0 };
+			bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "RTMESH01", 8) == 0 && fread(&n, 8, 1, f) == 1 && fread(flags, 4, 2, f) == 2 && n < (1ull << 28);
+			if (ok) { pos.resize((size_t)n * 9); ok = fread(pos.data(), 4, pos.size(), f) == pos.size(); }
+			if (ok && flags[0]) { uv.resize((size_t)n * 6); ok = fread(uv.data(), 4, uv.size(), f) == uv.size(); }
+			fclose(f);
+			if (!ok) throw std::runtime_error("malformed mesh file: " + path);
+			count = (size_t)n; hasUv = flags[0] != 0;
+		} else {
+			tj = &object["triangles"];
+			count = tj->size();
+			if (object.has("uvCoords")) { uvj = &object["uvCoords"]; hasUv = true; }
+		}
+	}
+	vec3 vertex(size_t i, int k) const {
+		if (tj) return to_vec3((*tj)[i][k]);
+		const float* p = pos.data() + i * 9 + k * 3;
+		return vec3(p[0], p[1], p[2]);
+	}
+	void uvOf(size_t i, float out[6]) const {
+		if (uvj) { const Value& u = (*uvj)[i]; for (int k = 0; k < 3; k++) { out[2 * k] = u[k][0].f32(); out[2 * k + 1] = u[k][1].f32(); } }
+		else if (!uv.empty()) memcpy(out, uv.data() + i * 6, 6 * sizeof(float));
+		else throw std::runtime_error("texturemesh without uvCoords");
+	}
+};
+
 struct Loader {
 	rt::FlatSceneStore* S;
 	std::string assetDir;
@@ -162,13 +204,14 @@ struct Loader {
 				node.kind = RT_CSG_BOX;
 				memcpy(node.f, box.b, sizeof box.b);
 			} else if (type.is("mesh")) {
-				const Value& tj = nj["triangles"];
+				MeshData md;
+				md.load(nj, assetDir);
 				rt_mesh m;
-				m.tri_first = (int32_t)S->mesh_tris.size(); m.tri_count = (int32_t)tj.size(); m.tex = -1; m.mat = 0;
+				m.tri_first = (int32_t)S->mesh_tris.size(); m.tri_count = (int32_t)md.count; m.tex = -1; m.mat = 0;
 				if (m.tri_count == 0) throw std::runtime_error("csg: mesh leaf without triangles");
 				int meshIdx = (int)S->meshes.size();
-				for (size_t i = 0; i < tj.size(); i++)
-					S->mesh_tris.push_back(makeTri(to_vec3(tj[i][0]), to_vec3(tj[i][1]), to_vec3(tj[i][2]), 0, meshIdx));
+				for (size_t i = 0; i < md.count; i++)
+					S->mesh_tris.push_back(makeTri(md.vertex(i, 0), md.vertex(i, 1), md.vertex(i, 2), 0, meshIdx));
 				S->meshes.push_back(m);
 				node.kind = RT_CSG_MESH; node.mesh = meshIdx;
 				box = meshBox(S->mesh_tris, (size_t)m.tri_first, (size_t)m.tri_count);
@@ -281,19 +324,20 @@ struct Loader {
 				p.id = planeId++; p.mat = mat;
 				S->planes.push_back(p);
 			} else if (type.is("mesh") || type.is("texturemesh")) {
-				const Value& tj = object["triangles"];
+				MeshData md;
+				md.load(object, assetDir);
 				bool textured = type.is("texturemesh");
 				rt_mesh m;
-				m.tri_first = (int32_t)S->mesh_tris.size(); m.tri_count = (int32_t)tj.size(); m.tex = -1; m.mat = mat;
+				m.tri_first = (int32_t)S->mesh_tris.size(); m.tri_count = (int32_t)md.count; m.tex = -1; m.mat = mat;
 				int meshIdx = (int)S->meshes.size();
 				if (textured) m.tex = addTexture(object["texture"].string());
-				for (size_t i = 0; i < tj.size(); i++) {
-					rt_tri t = makeTri(to_vec3(tj[i][0]), to_vec3(tj[i][1]), to_vec3(tj[i][2]), mat, meshIdx);
+				tris.reserve(tris.size() + md.count); S->mesh_tris.reserve(S->mesh_tris.size() + md.count); bvhObjs.reserve(bvhObjs.size() + md.count);
+				for (size_t i = 0; i < md.count; i++) {
+					rt_tri t = makeTri(md.vertex(i, 0), md.vertex(i, 1), md.vertex(i, 2), mat, meshIdx);
 					t.id = nextBvhId++;
 					if (textured) {   // raytracer.cpp:210-220
-						const Value& uvj = object["uvCoords"][i];
 						rt_uv uv;
-						for (int k = 0; k < 3; k++) { uv.uv[2 * k] = uvj[k][0].f32(); uv.uv[2 * k + 1] = uvj[k][1].f32(); }
+						md.uvOf(i, uv.uv);
 						t.uv = (int32_t)S->uvs.size();
 						S->uvs.push_back(uv);
 					}

@@ -151,7 +151,7 @@ int treeDepth(const rt_flat_scene* s) {
 	return maxDepth;
 }
 
-// A leaf whose primitives are 1..63 consecutive triangles: (first index in tris[], count); count 0 otherwise.
+// A leaf whose primitives are consecutive triangles: (first index in tris[], count); count 0 otherwise.
 struct TriRun { uint32_t first = 0, count = 0; };
 TriRun leafRun(const rt_flat_scene* s, int32_t leafRef) {
 	TriRun r;
@@ -162,12 +162,17 @@ TriRun leafRun(const rt_flat_scene* s, int32_t leafRef) {
 		if (r.count == 0) r.first = ix;
 		r.count++;
 		if (e & RT_PRIM_LAST) break;
-		if (r.count >= RT_TREELET_RUN_MAX) return TriRun{};
 	}
-	if (r.first >= RT_TREELET_EMBED - RT_TREELET_RUN_MAX) return TriRun{};
 	return r;
 }
-uint32_t externalAux(const TriRun& r) { return r.count ? (r.count << 26 | r.first) : RT_TREELET_NO_RUN; }
+// aux word of an external run (rt_kernels.h): short form for up to 63 triangles; long form (the count alone) when the
+// run's triangles sit at the same indices in tris[] as their entries in leaf_prims[], as in a triangles-only scene
+uint32_t externalAux(const TriRun& r, int32_t leafRef) {
+	if (r.count == 0) return RT_TREELET_NO_RUN;
+	if (r.count <= RT_TREELET_RUN_MAX && r.first < RT_TREELET_EMBED - RT_TREELET_RUN_MAX) return r.count << 26 | r.first;
+	if (r.first == (uint32_t)~leafRef && r.count < RT_TREELET_EMBED) return r.count;
+	return RT_TREELET_NO_RUN;
+}
 
 // Cuts the binary tree into treelets (layout in rt_kernels.h).  Returns the number of treelet levels.
 int buildTreelets(const rt_flat_scene* s, bool embed, std::vector<rt_bvh_node>& out, bool& externalRuns) {
@@ -180,7 +185,7 @@ int buildTreelets(const rt_flat_scene* s, bool embed, std::vector<rt_bvh_node>& 
 	struct Member { int32_t node; bool embedLeaf[2]; };
 	std::vector<Member> member;
 	// triangles a node brings along if all its run leaves of at most RT_TREELET_EMBED_MAX triangles are embedded
-	auto runOf = [&](int32_t c) { TriRun r = leafRun(s, c); if (!embed || r.count > RT_TREELET_EMBED_MAX) r.count = 0; return r; };
+	auto runOf = [&](int32_t c) { TriRun r = leafRun(s, c); if (!embed || r.count > RT_TREELET_EMBED_MAX || r.first >= RT_TREELET_EMBED) r.count = 0; return r; };
 	for (size_t t = 0; t < roots.size(); t++) {
 		out.resize((t + 1) * RT_TREELET_SLOTS, rt_bvh_node{});
 		const int level = roots[t].level;
@@ -227,7 +232,7 @@ int buildTreelets(const rt_flat_scene* s, bool embed, std::vector<rt_bvh_node>& 
 							tri.mesh = (int32_t)(r.first + j);
 							memcpy(&out[t * RT_TREELET_SLOTS + triSlot], &tri, sizeof tri);
 						}
-					} else { o.count[k] = (int32_t)externalAux(r); externalRuns |= r.count != 0; }
+					} else { o.count[k] = (int32_t)externalAux(r, c); externalRuns |= (uint32_t)o.count[k] != RT_TREELET_NO_RUN; }
 				} else if (childSlot[2 * i + k] >= 0) {
 					o.child[k] = (int32_t)(t * RT_TREELET_SLOTS + childSlot[2 * i + k]);
 					o.count[k] = 0;
@@ -507,7 +512,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 		if ((rc = sc->upload(treelets.data(), (int64_t)treelets.size(), &tl))) return fail(rc);
 		D.treelets = reinterpret_cast<const float4*>(tl);
 		D.treelet_root = s->root_child < 0 ? s->root_child : 0;
-		D.treelet_root_aux = (s->root_child < 0 && s->root_count > 0) ? externalAux(leafRun(s, s->root_child)) : RT_TREELET_NO_RUN;
+		D.treelet_root_aux = (s->root_child < 0 && s->root_count > 0) ? externalAux(leafRun(s, s->root_child), s->root_child) : RT_TREELET_NO_RUN;
 		if (D.treelet_root_aux != RT_TREELET_NO_RUN) D.treelet_staging = 1;
 	}
 	D.n_planes = s->n_planes; D.n_lights = s->n_lights;

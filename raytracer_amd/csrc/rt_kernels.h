@@ -26,7 +26,9 @@
 //   aux          for a leaf child whose primitives are 1..63 consecutive triangles (a "run"):
 //                  embedded run   count << 26 | RT_TREELET_EMBED | level << 4 | slot : its triangles sit in TRIANGLE
 //                                 slots slot .. slot+count-1 of this same treelet (`level` = the treelet's level)
-//                  external run   count << 26 | index of the first triangle in tris[] (< 2^25)
+//                  external run   count << 26 | index of the first triangle in tris[] (< 2^25), count 1..63; or, with
+//                                 those six bits zero, the count alone (< 2^25): a longer run whose triangles have the
+//                                 same indices in tris[] as their entries in leaf_prims[] (first = ~child)
 //                RT_TREELET_NO_RUN otherwise (the leaf is then read through leaf_prims)
 // A TRIANGLE slot is a copy of the rt_tri record with `mesh` replaced by the triangle's index in tris[].
 // Node slots come first; a treelet is filled breadth-first from its root, a node joining only if its own embeddable

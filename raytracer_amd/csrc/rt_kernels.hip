@@ -520,17 +520,18 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			else if (m1 != 0) { node = c1; info = i1; inSub = h1; popNext = false; }
 			TR(6, sp);
 		} else if (info != RT_TREELET_NO_RUN) {   // leaf made of consecutive triangles: no leaf_prims indirection
-			const uint32_t count = info >> 26;
+			const bool longRun = (info >> 26) == 0u;   // external run in its long form: info = count, first triangle = first leaf entry
+			const uint32_t count = longRun ? info : info >> 26;
 			TR(7, count);
 			const uint32_t key0 = (uint32_t)~node + 1u;
-			if (info & RT_TREELET_EMBED) {   // ... which arrived with the treelet
+			if (!longRun && (info & RT_TREELET_EMBED)) {   // ... which arrived with the treelet
 				const float4* q = L.level((info >> 4) & 15u) + (info & 15u) * 4u;
 				for (uint32_t k = 0; k < count; k++, q += 4) {
 					const float4 a = q[0], b = q[1], c = q[2], d = q[3];
 					packetTri<ANYHIT, COUNT>(S, T, inSub, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), key0 + k);
 				}
 			} else {   // ... fetched 16 at a time (64 lanes x 16 B) into the staging buffer
-				const uint32_t first = info & (RT_TREELET_EMBED - 1u);
+				const uint32_t first = longRun ? (uint32_t)~node : info & (RT_TREELET_EMBED - 1u);
 				float4* buf = L.treelet + L.staging * 64u;
 				for (uint32_t k0 = 0; k0 < count; k0 += 16u) {
 					const uint32_t nb = count - k0 < 16u ? count - k0 : 16u;

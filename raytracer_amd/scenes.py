@@ -93,6 +93,20 @@ def _mesh_json(tris, uvs=None):
     return out
 
 
+def _mesh_file(out_dir, name, tris, uvs=None):
+    """The same triangles as _mesh_json, as the loader's binary mesh file (scene_loader.cpp, MeshData): {"file": name}.
+    Values go through the same 7-decimal rounding as the JSON text, so both forms load to bit-identical scenes."""
+    pos = tris.astype(np.float64).round(7).astype("<f4")
+    with open(os.path.join(out_dir, name), "wb") as f:
+        f.write(b"RTMESH01")
+        f.write(np.array([len(pos)], "<u8").tobytes())
+        f.write(np.array([1 if uvs is not None else 0, 0], "<u4").tobytes())
+        f.write(np.ascontiguousarray(pos).tobytes())
+        if uvs is not None:
+            f.write(np.ascontiguousarray(uvs.astype(np.float64).round(7).astype("<f4")).tobytes())
+    return {"file": name}
+
+
 def c2_scene(out_dir, grid=224):
     """BASELINE config 2: textured triangle mesh (grid*grid*2 triangles, 224 -> 100 352) with bump mapping."""
     os.makedirs(out_dir, exist_ok=True)
@@ -202,19 +216,21 @@ def c4_scene(out_dir, samples=64):
     return path
 
 
-def c5_scene(out_dir, grid=1581):
+def c5_scene(out_dir, grid=1581, binary=None):
     """BASELINE config 5: height field of grid*grid*2 triangles (1581 -> 4 999 122) + floor + two lights.
-    The JSON is ~0.6 GB at full size; pass a smaller grid for tests."""
+    As JSON text the mesh is ~0.6 GB at full size; `binary` (default: above 400 k triangles) writes it as a mesh file."""
     os.makedirs(out_dir, exist_ok=True)
     tris, _ = height_field(grid, seed=2)
+    if binary is None:
+        binary = len(tris) > 400000
     mesh = {"type": "mesh", "material": {"ambient": [0.1, 0.12, 0.1], "diffuse": [0.45, 0.6, 0.4], "specular": [0.2, 0.2, 0.2], "shininess": 8.0}}
-    mesh.update(_mesh_json(tris))
+    mesh.update(_mesh_file(out_dir, f"c5_{grid}.bin", tris) if binary else _mesh_json(tris))
     scene = {"camera": {"field": 60, "background": [0.3, 0.4, 0.6]},
              "objects": [mesh, {"type": "plane", "position": [0, -1.6, 0], "normal": [0, 1, 0], "material": {"diffuse": [0.3, 0.3, 0.35]}}],
              "lights": [{"type": "ambient", "color": [0.25, 0.25, 0.25]},
                         {"type": "directional", "color": [0.7, 0.7, 0.65], "direction": [-0.4, -1.0, -0.3]},
                         {"type": "point", "color": [0.5, 0.45, 0.4], "position": [2.0, 4.0, -3.0]}]}
-    path = os.path.join(out_dir, f"c5_{grid}.json")
+    path = os.path.join(out_dir, f"c5_{grid}{'_bin' if binary else ''}.json")
     with open(path, "w") as f:
         json.dump(scene, f)
     return path

@@ -165,3 +165,33 @@ def test_synthetic_config_scenes_load_and_match_oracle_counts(tmp_path):
         cam = rt.Camera(fs.fov, 48, 27)
         img, nn, ns = oracle.render(fs, cam, 48, 27, max_depth=5, seed=3)
         assert nn >= 48 * 27 and np.isfinite(img).all() and img.max() > 0.05
+
+
+def test_binary_mesh_file_loads_to_the_same_scene_as_json(tmp_path):
+    """"file": mesh.bin is an additive form of "triangles"/"uvCoords"; both give bit-identical flat scenes."""
+    from raytracer_amd import scenes
+    a = rt.FlatScene.from_json(scenes.c5_scene(str(tmp_path), grid=40, binary=False))
+    b = rt.FlatScene.from_json(scenes.c5_scene(str(tmp_path), grid=40, binary=True))
+    a.save(str(tmp_path / "a.rtscene")); b.save(str(tmp_path / "b.rtscene"))
+    assert (tmp_path / "a.rtscene").read_bytes() == (tmp_path / "b.rtscene").read_bytes()
+    # textured meshes carry their uv block
+    import json, numpy as np
+    tris, uvs = scenes.height_field(6, seed=3)
+    scenes.write_bmp24(str(tmp_path / "t.bmp"), scenes.tiles_texture(64, 4))
+    base = {"camera": {"field": 60, "background": [0, 0, 0]}, "lights": [{"type": "ambient", "color": [1, 1, 1]}]}
+    mj = {"type": "texturemesh", "texture": "t.bmp", "material": {}}
+    mj.update(scenes._mesh_json(tris, uvs))
+    mf = {"type": "texturemesh", "texture": "t.bmp", "material": {}}
+    mf.update(scenes._mesh_file(str(tmp_path), "m.bin", tris, uvs))
+    for name, mesh in (("j", mj), ("f", mf)):
+        (tmp_path / f"{name}.json").write_text(json.dumps(dict(base, objects=[mesh])))
+        rt.FlatScene.from_json(str(tmp_path / f"{name}.json")).save(str(tmp_path / f"{name}.rtscene"))
+    assert (tmp_path / "j.rtscene").read_bytes() == (tmp_path / "f.rtscene").read_bytes()
+    # a missing or truncated file is an error, not a crash
+    (tmp_path / "bad.json").write_text(json.dumps(dict(base, objects=[{"type": "mesh", "material": {}, "file": "nope.bin"}])))
+    with pytest.raises(rt.capi.RtError):
+        rt.FlatScene.from_json(str(tmp_path / "bad.json"))
+    (tmp_path / "short.bin").write_bytes((tmp_path / "m.bin").read_bytes()[:100])
+    (tmp_path / "short.json").write_text(json.dumps(dict(base, objects=[{"type": "mesh", "material": {}, "file": "short.bin"}])))
+    with pytest.raises(rt.capi.RtError):
+        rt.FlatScene.from_json(str(tmp_path / "short.json"))

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Frame times of the BASELINE.json configurations other than the bench one (C3, C4, C5 at a reduced triangle count)."""
+import os, sys, time, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import raytracer_amd as rt
+from raytracer_amd import scenes
+
+def run(name, path, W, H, aa=(1, 1), max_depth=16, eye=(0, 0, 0), rot_x=0.0, reps=5):
+    t0 = time.perf_counter()
+    flat = rt.FlatScene.from_json(path)
+    t_load = time.perf_counter() - t0
+    sc = rt.Scene(flat, 0)
+    cam = rt.Camera(flat.fov, W, H, eye=eye, rot_x=rot_x)
+    frame = torch.zeros(H, W, 3, device="cuda")
+    sc.render_into(frame.data_ptr(), W, H, aa=aa, camera=cam, max_depth=max_depth)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        st = sc.render_into(frame.data_ptr(), W, H, aa=aa, camera=cam, max_depth=max_depth)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+    rays = st["rays_nearest"] + st["rays_shadow"]
+    print(f"{name}: load {t_load:.1f} s, {dt * 1e3:.2f} ms/frame, {rays / 1e6:.1f} Mrays ({st['rays_nearest'] / 1e6:.1f} nearest), {rays / dt / 1e6:.0f} Mrays/s, levels {st['levels']}, splits {st['batch_splits']}", flush=True)
+    sc.close()
+
+with tempfile.TemporaryDirectory() as tmp:
+    run("C3 csg 1080p depth5", scenes.c3_scene(tmp), 1920, 1080, max_depth=5, eye=(0, 1.0, 2.0), rot_x=-0.25)
+    run("C4 area 64 1080p", scenes.c4_scene(tmp, 64), 1920, 1080)
+    g = int(os.environ.get("C5_GRID", "500"))
+    run(f"C5 grid {g} 4K 2x2", scenes.c5_scene(tmp, g), 3840, 2160, aa=(2, 2), eye=(0, 1.5, 1.0), rot_x=-0.3, reps=2)

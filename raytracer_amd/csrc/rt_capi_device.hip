@@ -6,6 +6,7 @@
 #include "host/host_internal.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -174,41 +175,149 @@ uint32_t externalAux(const TriRun& r, int32_t leafRef) {
 	return RT_TREELET_NO_RUN;
 }
 
-// Cuts the binary tree into treelets (layout in rt_kernels.h).  Returns the number of treelet levels.
-int buildTreelets(const rt_flat_scene* s, bool embed, std::vector<rt_bvh_node>& out, bool& externalRuns) {
+// The tree the packet kernels walk: the reference's nodes, plus -- below every leaf of more than RT_TREELET_EMBED_MAX
+// consecutive triangles -- a small tree over that leaf's triangles.  The reference's build stops at depth 16
+// (bvh.h:6), which leaves ~76 triangles per leaf in a 5 M-triangle mesh, and it tests all of them for every ray that
+// enters the leaf's box.  What it returns from a leaf is a pure function of the triangles' own hit tests -- the
+// nearest t above 1e-5, first in leaf order among equals; for shadows the product over all triangles hit before the
+// light -- so any way of skipping triangles that certainly cannot be hit returns the same.  The sub-tree's boxes are
+// therefore CONSERVATIVE (slightly inflated, and a test too close to call counts as a hit, RT_TREELET_CONS), unlike
+// the reference's own boxes above them, whose exact floating-point verdicts are part of its result.
+struct AugTree {
+	struct Node { float box[2][6]; int32_t child[2]; bool cons; };   // child >= 0: node; < 0: ~index into leaves
+	struct Leaf { int32_t ref; bool sub; uint32_t first, count; };   // !sub: the reference leaf `ref` (run first/count, count 0 = not a run); sub: subTris[first .. first+count)
+	std::vector<Node> nodes;
+	std::vector<Leaf> leaves;
+	std::vector<uint32_t> subTris;   // triangle indices
+	std::vector<uint32_t> subKeys;   // ... and their tie-break keys (position in leaf_prims + 1)
+	int32_t root = -1;
+	int depth = 0;
+};
+
+void triBounds(const rt_tri& t, float lo[3], float hi[3]) {
+	for (int a = 0; a < 3; a++) { lo[a] = std::min({ t.p0[a], t.p1[a], t.p2[a] }); hi[a] = std::max({ t.p0[a], t.p1[a], t.p2[a] }); }
+}
+// bounds of subTris[first, first+count), inflated so that no hit the triangle test accepts can fall outside
+void subBox(const rt_flat_scene* s, const AugTree& A, uint32_t first, uint32_t count, float box[6]) {
+	float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
+	for (uint32_t i = 0; i < count; i++) {
+		float l[3], h[3];
+		triBounds(s->tris[A.subTris[first + i]], l, h);
+		for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); }
+	}
+	for (int a = 0; a < 3; a++) {
+		const float pad = 1e-5f * std::max({ fabsf(lo[a]), fabsf(hi[a]), hi[a] - lo[a] }) + 1e-6f;
+		box[2 * a] = lo[a] - pad; box[2 * a + 1] = hi[a] + pad;
+	}
+}
+// median split on the longest axis of the centroid bounds; returns a child reference
+int32_t buildSub(const rt_flat_scene* s, AugTree& A, uint32_t first, uint32_t count, int depth, int& maxDepth) {
+	maxDepth = std::max(maxDepth, depth);
+	if (count <= RT_TREELET_SUBLEAF_MAX) {
+		A.leaves.push_back({ 0, true, first, count });
+		return ~(int32_t)(A.leaves.size() - 1);
+	}
+	float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
+	auto centroid = [&](uint32_t tri, int a) { const rt_tri& t = s->tris[tri]; return (t.p0[a] + t.p1[a] + t.p2[a]) * (1.0f / 3.0f); };
+	for (uint32_t i = 0; i < count; i++)
+		for (int a = 0; a < 3; a++) { const float c = centroid(A.subTris[first + i], a); lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c); }
+	int axis = 0;
+	if (hi[1] - lo[1] > hi[axis] - lo[axis]) axis = 1;
+	if (hi[2] - lo[2] > hi[axis] - lo[axis]) axis = 2;
+	// order triangle indices and keys together
+	std::vector<std::pair<uint32_t, uint32_t>> tmp(count);
+	for (uint32_t i = 0; i < count; i++) tmp[i] = { A.subTris[first + i], A.subKeys[first + i] };
+	const uint32_t half = count / 2;
+	std::nth_element(tmp.begin(), tmp.begin() + half, tmp.end(), [&](const auto& x, const auto& y) {
+		const float cx = centroid(x.first, axis), cy = centroid(y.first, axis);
+		return cx < cy || (cx == cy && x.second < y.second);
+	});
+	for (uint32_t i = 0; i < count; i++) { A.subTris[first + i] = tmp[i].first; A.subKeys[first + i] = tmp[i].second; }
+	const int32_t me = (int32_t)A.nodes.size();
+	A.nodes.push_back({});
+	AugTree::Node n{};
+	n.cons = true;
+	subBox(s, A, first, half, n.box[0]);
+	subBox(s, A, first + half, count - half, n.box[1]);
+	n.child[0] = buildSub(s, A, first, half, depth + 1, maxDepth);
+	n.child[1] = buildSub(s, A, first + half, count - half, depth + 1, maxDepth);
+	A.nodes[me] = n;
+	return me;
+}
+
+void buildAugTree(const rt_flat_scene* s, bool split, AugTree& A) {
+	A = AugTree{};
+	if (s->root_child < 0) return;
+	A.root = s->root_child;
+	A.nodes.resize((size_t)s->n_bvh_nodes);
+	// depths of the reference nodes (children follow their parents in the pre-order array)
+	std::vector<int> depthOf((size_t)s->n_bvh_nodes, 0);
+	depthOf[(size_t)s->root_child] = 1;
+	for (int32_t i = 0; i < s->n_bvh_nodes; i++) {
+		const rt_bvh_node& b = s->bvh_nodes[i];
+		AugTree::Node n{};
+		memcpy(n.box, b.box, sizeof n.box);
+		n.cons = false;
+		for (int k = 0; k < 2; k++) {
+			const int32_t c = b.child[k];
+			if (c >= 0) { n.child[k] = c; depthOf[(size_t)c] = depthOf[(size_t)i] + 1; continue; }
+			const TriRun r = leafRun(s, c);
+			if (split && r.count > RT_TREELET_EMBED_MAX) {
+				const uint32_t first = (uint32_t)A.subTris.size();
+				for (uint32_t j = 0; j < r.count; j++) { A.subTris.push_back(r.first + j); A.subKeys.push_back((uint32_t)~c + j + 1u); }
+				int maxDepth = 0;
+				n.child[k] = buildSub(s, A, first, r.count, depthOf[(size_t)i] + 1, maxDepth);
+				A.depth = std::max(A.depth, maxDepth);
+			} else {
+				A.leaves.push_back({ c, false, r.first, r.count });
+				n.child[k] = ~(int32_t)(A.leaves.size() - 1);
+				A.depth = std::max(A.depth, depthOf[(size_t)i] + 1);
+			}
+		}
+		A.nodes[(size_t)i] = n;
+	}
+}
+
+// Cuts the augmented tree into treelets (layout in rt_kernels.h).  Returns the number of treelet levels.
+int buildTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std::vector<rt_bvh_node>& out, bool& externalRuns) {
 	out.clear();
 	externalRuns = false;
-	if (s->root_child < 0) return 0;
+	if (A.root < 0) return 0;
 	struct Root { int32_t node; int level; };
-	std::vector<Root> roots{ { s->root_child, 0 } };
+	std::vector<Root> roots{ { A.root, 0 } };
 	int levels = 0;
 	struct Member { int32_t node; bool embedLeaf[2]; };
 	std::vector<Member> member;
-	// triangles a node brings along if all its run leaves of at most RT_TREELET_EMBED_MAX triangles are embedded
-	auto runOf = [&](int32_t c) { TriRun r = leafRun(s, c); if (!embed || r.count > RT_TREELET_EMBED_MAX || r.first >= RT_TREELET_EMBED) r.count = 0; return r; };
+	// triangles a leaf brings into the treelet if it is embedded: sub-leaves always, reference runs up to RT_TREELET_EMBED_MAX
+	auto embeddable = [&](int32_t c) -> uint32_t {
+		const AugTree::Leaf& L = A.leaves[(size_t)~c];
+		if (L.sub) return L.count;
+		return (embed && L.count > 0 && L.count <= RT_TREELET_EMBED_MAX && L.first < RT_TREELET_EMBED) ? L.count : 0u;
+	};
 	for (size_t t = 0; t < roots.size(); t++) {
 		out.resize((t + 1) * RT_TREELET_SLOTS, rt_bvh_node{});
 		const int level = roots[t].level;
 		levels = std::max(levels, level + 1);
 		member.clear();
 		uint32_t used = 0;
-		std::vector<std::pair<size_t, int>> exits;   // (member, child) that root further treelets, in creation order
 		auto join = [&](int32_t node, bool must) {
-			const rt_bvh_node& b = s->bvh_nodes[node];
+			const AugTree::Node& b = A.nodes[(size_t)node];
 			uint32_t tris[2] = { 0, 0 };
-			for (int k = 0; k < 2; k++) if (b.child[k] < 0) tris[k] = runOf(b.child[k]).count;
+			bool sub = false;
+			for (int k = 0; k < 2; k++) if (b.child[k] < 0) { tris[k] = embeddable(b.child[k]); sub |= A.leaves[(size_t)~b.child[k]].sub; }
 			if (!must && used + 1 + tris[0] + tris[1] > RT_TREELET_SLOTS) return false;
 			Member m{ node, { false, false } };
 			used += 1;
-			for (int k = 0; k < 2; k++)   // the root joins whatever it brings; its runs are embedded while they fit
+			for (int k = 0; k < 2; k++)   // the root joins whatever it brings; its runs are embedded while they fit (sub-leaves always do)
 				if (tris[k] && used + tris[k] <= RT_TREELET_SLOTS) { m.embedLeaf[k] = true; used += tris[k]; }
+			(void)sub;
 			member.push_back(m);
 			return true;
 		};
 		join(roots[t].node, true);
 		std::vector<int32_t> childSlot;   // per member, per child: slot of an in-treelet inner child, -1 otherwise
 		for (size_t i = 0; i < member.size(); i++) {
-			const rt_bvh_node& b = s->bvh_nodes[member[i].node];
+			const AugTree::Node& b = A.nodes[(size_t)member[i].node];
 			for (int k = 0; k < 2; k++) {
 				int32_t slot = -1;
 				if (b.child[k] >= 0 && join(b.child[k], false)) slot = (int32_t)member.size() - 1;
@@ -217,29 +326,36 @@ int buildTreelets(const rt_flat_scene* s, bool embed, std::vector<rt_bvh_node>& 
 		}
 		uint32_t triSlot = (uint32_t)member.size();
 		for (size_t i = 0; i < member.size(); i++) {
-			const rt_bvh_node& b = s->bvh_nodes[member[i].node];
+			const AugTree::Node& b = A.nodes[(size_t)member[i].node];
 			rt_bvh_node& o = out[t * RT_TREELET_SLOTS + i];
 			memcpy(o.box, b.box, sizeof o.box);
 			for (int k = 0; k < 2; k++) {
 				const int32_t c = b.child[k];
 				if (c < 0) {
-					const TriRun r = leafRun(s, c);
-					o.child[k] = c;
+					const AugTree::Leaf& L = A.leaves[(size_t)~c];
+					o.child[k] = L.sub ? -1 : L.ref;
 					if (member[i].embedLeaf[k]) {
-						o.count[k] = (int32_t)(r.count << 26 | RT_TREELET_EMBED | (uint32_t)level << 4 | triSlot);
-						for (uint32_t j = 0; j < r.count; j++, triSlot++) {
-							rt_tri tri = s->tris[r.first + j];
-							tri.mesh = (int32_t)(r.first + j);
+						o.count[k] = (int32_t)(L.count << 26 | RT_TREELET_EMBED | (uint32_t)level << 4 | triSlot);
+						for (uint32_t j = 0; j < L.count; j++, triSlot++) {
+							const uint32_t index = L.sub ? A.subTris[L.first + j] : L.first + j;
+							rt_tri tri = s->tris[index];
+							tri.mesh = (int32_t)index;                                                             // -> T.best
+							tri.uv = (int32_t)(L.sub ? A.subKeys[L.first + j] : (uint32_t)~L.ref + j + 1u);      // -> tie-break key
 							memcpy(&out[t * RT_TREELET_SLOTS + triSlot], &tri, sizeof tri);
 						}
-					} else { o.count[k] = (int32_t)externalAux(r, c); externalRuns |= (uint32_t)o.count[k] != RT_TREELET_NO_RUN; }
-				} else if (childSlot[2 * i + k] >= 0) {
-					o.child[k] = (int32_t)(t * RT_TREELET_SLOTS + childSlot[2 * i + k]);
-					o.count[k] = 0;
+					} else {
+						if (L.sub) { rt::set_error("internal: a sub-leaf did not fit its treelet"); return -1; }
+						o.count[k] = (int32_t)externalAux(TriRun{ L.first, L.count }, L.ref);
+						externalRuns |= (uint32_t)o.count[k] != RT_TREELET_NO_RUN;
+					}
 				} else {
-					o.child[k] = (int32_t)(roots.size() * RT_TREELET_SLOTS);
+					const uint32_t flag = A.nodes[(size_t)c].cons ? RT_TREELET_CONS : 0u;
+					if (childSlot[2 * i + k] >= 0) o.child[k] = (int32_t)((uint32_t)(t * RT_TREELET_SLOTS + childSlot[2 * i + k]) | flag);
+					else {
+						o.child[k] = (int32_t)((uint32_t)(roots.size() * RT_TREELET_SLOTS) | flag);
+						roots.push_back({ c, level + 1 });
+					}
 					o.count[k] = 0;
-					roots.push_back({ c, level + 1 });
 				}
 			}
 		}
@@ -503,9 +619,13 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 		static_assert(sizeof(rt_tri) == sizeof(rt_bvh_node) && sizeof(rt_bvh_node) == 64, "treelet slots are 64 B");
 		std::vector<rt_bvh_node> treelets;
 		bool externalRuns = false;
-		int levels = buildTreelets(s, getenv("RT_NO_EMBED") == nullptr, treelets, externalRuns);
-		if (levels > RT_TREELET_MAX_LEVELS) levels = buildTreelets(s, false, treelets, externalRuns);
-		if (levels > RT_TREELET_MAX_LEVELS || treelets.size() / RT_TREELET_SLOTS >= (1u << 27)) { rt::set_error("BVH too deep or too large for the treelet layout"); return fail(RT_ELIMIT); }
+		AugTree aug;
+		buildAugTree(s, getenv("RT_NO_SPLIT") == nullptr, aug);
+		if (aug.depth > RT_PACKET_STACK_DEPTH) buildAugTree(s, false, aug);   // (a leaf of > 4 * 2^20 triangles)
+		int levels = buildTreelets(s, aug, getenv("RT_NO_EMBED") == nullptr, treelets, externalRuns);
+		if (levels > RT_TREELET_MAX_LEVELS) { buildAugTree(s, false, aug); levels = buildTreelets(s, aug, false, treelets, externalRuns); }
+		if (levels < 0) return fail(RT_EINVAL);
+		if (levels > RT_TREELET_MAX_LEVELS || treelets.size() / RT_TREELET_SLOTS >= RT_TREELET_CONS / RT_TREELET_SLOTS) { rt::set_error("BVH too deep or too large for the treelet layout"); return fail(RT_ELIMIT); }
 		D.treelet_levels = levels;
 		D.treelet_staging = externalRuns ? 1 : 0;
 		const rt_bvh_node* tl = nullptr;

@@ -30,7 +30,8 @@
 //                                 those six bits zero, the count alone (< 2^25): a longer run whose triangles have the
 //                                 same indices in tris[] as their entries in leaf_prims[] (first = ~child)
 //                RT_TREELET_NO_RUN otherwise (the leaf is then read through leaf_prims)
-// A TRIANGLE slot is a copy of the rt_tri record with `mesh` replaced by the triangle's index in tris[].
+// A TRIANGLE slot is a copy of the rt_tri record with `mesh` replaced by the triangle's index in tris[] and `uv` by its
+// tie-break key (position in leaf_prims + 1).
 // Node slots come first; a treelet is filled breadth-first from its root, a node joining only if its own embeddable
 // leaves fit as well, so a whole bottom subtree (nodes + triangles) arrives with one fetch.
 #define RT_TREELET_SLOTS 16
@@ -38,8 +39,11 @@
 #define RT_TREELET_NO_RUN 0xffffffffu
 #define RT_TREELET_EMBED (1u << 25)
 #define RT_TREELET_RUN_MAX 63u
-#define RT_TREELET_EMBED_MAX 8u           /* longest run that is embedded */
-#define RT_PACKET_STACK_BYTES (RT_STACK_DEPTH * 16)
+#define RT_TREELET_EMBED_MAX 8u           /* longest run that is embedded; longer all-triangle leaves get a sub-tree */
+#define RT_TREELET_SUBLEAF_MAX 4u         /* triangles per leaf of such a sub-tree */
+#define RT_TREELET_CONS (1u << 29)        /* flag on a child reference: the node belongs to a sub-tree, its box tests are conservative */
+#define RT_PACKET_STACK_DEPTH 40          /* wave stack entries: reference depth <= RT_STACK_DEPTH plus the sub-trees */
+#define RT_PACKET_STACK_BYTES (RT_PACKET_STACK_DEPTH * 16)
 // LDS of a packet kernel's workgroup: the root treelet once (every packet starts there; fetched when the workgroup
 // starts), then per wave one 1 KB buffer per deeper treelet level, one more when the scene has external runs to stage,
 // and the stack

@@ -400,7 +400,7 @@ struct Tracer;
 struct PacketLds {
 	float4* root;               // [64] the root treelet, shared by the workgroup's waves
 	float4* treelet;            // [levels - 1 (+ 1)][64]: this wave's buffer per deeper treelet level, then the staging buffer
-	uint32_t (*stack)[4];       // [kStack]: node, lane mask lo/hi, level (inner) or aux (leaf)
+	uint32_t (*stack)[4];       // [RT_PACKET_STACK_DEPTH]: node, lane mask lo/hi, level (inner) or aux (leaf)
 	uint32_t staging;           // index of the staging buffer in treelet[]
 	__device__ __forceinline__ float4* level(uint32_t l) const { return l == 0 ? root : treelet + (l - 1u) * 64u; }
 };
@@ -474,13 +474,15 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 #if RT_PROF
 			T.steps++;
 #endif
+			const bool cons = ((uint32_t)node & RT_TREELET_CONS) != 0u;   // a node of a sub-tree under a fat leaf: conservative box tests
+			const int32_t nidx = (int32_t)((uint32_t)node & (RT_TREELET_CONS - 1u));
 			float4* buf = L.level(info);
-			if ((node & (RT_TREELET_SLOTS - 1)) == 0 && node != 0) {   // the root of a deeper treelet: stage it
-				buf[lane] = S.treelets[(size_t)node * 4 + lane];
+			if ((nidx & (RT_TREELET_SLOTS - 1)) == 0 && nidx != 0) {   // the root of a deeper treelet: stage it
+				buf[lane] = S.treelets[(size_t)nidx * 4 + lane];
 				__builtin_amdgcn_wave_barrier();
-				TR(4, node >> 4);
+				TR(4, nidx >> 4);
 			}
-			const float4* q = buf + (node & (RT_TREELET_SLOTS - 1)) * 4;
+			const float4* q = buf + (nidx & (RT_TREELET_SLOTS - 1)) * 4;
 			const float4 a = q[0], b = q[1], c = q[2], d = q[3];
 			const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
 			const float b1[6] = { b.z, b.w, c.x, c.y, c.z, c.w };
@@ -496,20 +498,21 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			h0 = h0 && inSub && !T.special; h1 = h1 && inSub && !T.special;
 			a0 = (a0 || T.special) && inSub; a1 = (a1 || T.special) && inSub;
 			if (COUNT || RT_PROF) T.cntNodes += inSub ? 1u : 0u;
-			if (__ballot(a0 || a1) != 0) {   // too close to call somewhere in the wave (rare): the reference's own arithmetic decides
+			if (cons) { h0 = h0 || a0; h1 = h1 || a1; }   // too close to call = visit
+			else if (__ballot(a0 || a1) != 0) {   // too close to call somewhere in the wave (rare): the reference's own arithmetic decides
 				if (a0) { const float t = boxIntersect(b0, T.e, T.d, false); h0 = !(t < 0 || t > tlimit); }
 				if (a1) { const float t = boxIntersect(b1, T.e, T.d, false); h1 = !(t < 0 || t > tlimit); }
 			}
 			const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
 			TR(5, __popcll(m0 | m1));
 			// what travels with a child: its treelet level (one more when it roots another treelet) or its leaf aux word
-			const uint32_t i0 = c0 < 0 ? x0 : info + (((c0 ^ node) >> 4) != 0);
-			const uint32_t i1 = c1 < 0 ? x1 : info + (((c1 ^ node) >> 4) != 0);
+			const uint32_t i0 = c0 < 0 ? x0 : info + (((((uint32_t)c0 & (RT_TREELET_CONS - 1u)) ^ (uint32_t)nidx) >> 4) != 0);
+			const uint32_t i1 = c1 < 0 ? x1 : info + (((((uint32_t)c1 & (RT_TREELET_CONS - 1u)) ^ (uint32_t)nidx) >> 4) != 0);
 			if (m0 != 0 && m1 != 0) {
 				// visit first the child most rays reach first (any order is correct; ties go to the reference's order by key)
 				const bool swap = 2 * __popcll(__ballot(h0 && h1 && t1 < t0)) > __popcll(m0 & m1);
 				const unsigned long long mFar = swap ? m0 : m1;
-				if (sp < kStack) {
+				if (sp < RT_PACKET_STACK_DEPTH) {
 					*reinterpret_cast<uint4*>(L.stack[sp]) = make_uint4((uint32_t)(swap ? c0 : c1), (uint32_t)mFar, (uint32_t)(mFar >> 32), swap ? i0 : i1);
 					sp++;
 				}
@@ -528,7 +531,7 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 				const float4* q = L.level((info >> 4) & 15u) + (info & 15u) * 4u;
 				for (uint32_t k = 0; k < count; k++, q += 4) {
 					const float4 a = q[0], b = q[1], c = q[2], d = q[3];
-					packetTri<ANYHIT, COUNT>(S, T, inSub, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), key0 + k);
+					packetTri<ANYHIT, COUNT>(S, T, inSub, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), __float_as_uint(d.w));   // slot = triangle, material, index, key
 				}
 			} else {   // ... fetched 16 at a time (64 lanes x 16 B) into the staging buffer
 				const uint32_t first = longRun ? (uint32_t)~node : info & (RT_TREELET_EMBED - 1u);

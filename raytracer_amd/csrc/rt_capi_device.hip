@@ -278,6 +278,76 @@ void buildAugTree(const rt_flat_scene* s, bool split, AugTree& A) {
 	}
 }
 
+// Trees for Mesh::rayhit (meshHit, rt_device.h): for every mesh that can be asked for a hit on its own -- a CSG leaf, or
+// a mesh whose material transmits (Object::transmitRay looks for the exit on the mesh) -- and has enough triangles for
+// a tree to pay.  Median split over triangle centroids, conservative (inflated) boxes, leaves of up to 4 triangles
+// listed as offsets into the mesh's triangles.
+struct MeshTrees {
+	std::vector<rt_bvh_node> nodes;
+	std::vector<int32_t> order, roots;
+	int depth = 0;
+};
+void meshBox(const rt_tri* tris, const int32_t* idx, int count, float box[6]) {
+	float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
+	for (int i = 0; i < count; i++) {
+		float l[3], h[3];
+		triBounds(tris[idx[i]], l, h);
+		for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); }
+	}
+	for (int a = 0; a < 3; a++) {
+		const float pad = 1e-5f * std::max({ fabsf(lo[a]), fabsf(hi[a]), hi[a] - lo[a] }) + 1e-6f;
+		box[2 * a] = lo[a] - pad; box[2 * a + 1] = hi[a] + pad;
+	}
+}
+// builds the subtree over order[first, first+count) (count > 4); returns its node index
+int32_t buildMeshNode(const rt_tri* tris, MeshTrees& M, int first, int count, int depth) {
+	M.depth = std::max(M.depth, depth);
+	int32_t* idx = M.order.data() + first;
+	float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
+	auto centroid = [&](int32_t i, int a) { const rt_tri& t = tris[i]; return (t.p0[a] + t.p1[a] + t.p2[a]) * (1.0f / 3.0f); };
+	for (int i = 0; i < count; i++)
+		for (int a = 0; a < 3; a++) { const float c = centroid(idx[i], a); lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c); }
+	int axis = 0;
+	if (hi[1] - lo[1] > hi[axis] - lo[axis]) axis = 1;
+	if (hi[2] - lo[2] > hi[axis] - lo[axis]) axis = 2;
+	const int half = count / 2;
+	std::nth_element(idx, idx + half, idx + count, [&](int32_t x, int32_t y) {
+		const float cx = centroid(x, axis), cy = centroid(y, axis);
+		return cx < cy || (cx == cy && x < y);
+	});
+	const int32_t me = (int32_t)M.nodes.size();
+	M.nodes.push_back(rt_bvh_node{});
+	rt_bvh_node n{};
+	const int part[2][2] = { { first, half }, { first + half, count - half } };
+	for (int k = 0; k < 2; k++) {
+		meshBox(tris, M.order.data() + part[k][0], part[k][1], n.box[k]);
+		if (part[k][1] <= 4) { n.child[k] = ~part[k][0]; n.count[k] = part[k][1]; }
+		else { n.child[k] = buildMeshNode(tris, M, part[k][0], part[k][1], depth + 1); n.count[k] = 0; }
+	}
+	M.nodes[(size_t)me] = n;
+	return me;
+}
+void buildMeshTrees(const rt_flat_scene* s, MeshTrees& M) {
+	M = MeshTrees{};
+	M.roots.assign((size_t)std::max(s->n_meshes, 1), -1);
+	if (getenv("RT_NO_MESH_TREES")) return;
+	std::vector<char> wanted((size_t)s->n_meshes, 0);
+	for (int32_t i = 0; i < s->n_csg_nodes; i++)
+		if (s->csg_nodes[i].kind == RT_CSG_MESH && s->csg_nodes[i].mesh >= 0 && s->csg_nodes[i].mesh < s->n_meshes) wanted[(size_t)s->csg_nodes[i].mesh] = 1;
+	for (int32_t i = 0; i < s->n_meshes; i++) {
+		const float* kt = s->materials[s->meshes[i].mat].transmissive;
+		if (kt[0] != 0 || kt[1] != 0 || kt[2] != 0) wanted[(size_t)i] = 1;
+	}
+	for (int32_t i = 0; i < s->n_meshes; i++) {
+		const rt_mesh& m = s->meshes[i];
+		if (!wanted[(size_t)i] || m.tri_count < 32) continue;
+		const int first = (int)M.order.size();
+		for (int j = 0; j < m.tri_count; j++) M.order.push_back(j);
+		M.roots[(size_t)i] = buildMeshNode(s->mesh_tris + m.tri_first, M, first, m.tri_count, 1);
+	}
+	if (M.depth > RT_MESH_STACK) { M.nodes.clear(); M.order.clear(); M.roots.assign(M.roots.size(), -1); }   // (a degenerate mesh: keep the scan)
+}
+
 // Cuts the augmented tree into treelets (layout in rt_kernels.h).  Returns the number of treelet levels.
 int buildTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std::vector<rt_bvh_node>& out, bool& externalRuns) {
 	out.clear();
@@ -615,6 +685,13 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	if ((rc = sc->upload(s->texels, s->n_texel_bytes, &D.texels))) return fail(rc);
 	if ((rc = sc->upload(s->bvh_nodes, s->n_bvh_nodes, &D.nodes))) return fail(rc);
 	if ((rc = sc->upload(s->leaf_prims, s->n_leaf_prims, &D.leaf_prims))) return fail(rc);
+	{
+		MeshTrees mt;
+		buildMeshTrees(s, mt);
+		if ((rc = sc->upload(mt.nodes.data(), (int64_t)mt.nodes.size(), &D.mesh_nodes))) return fail(rc);
+		if ((rc = sc->upload(mt.order.data(), (int64_t)mt.order.size(), &D.mesh_order))) return fail(rc);
+		if ((rc = sc->upload(mt.roots.data(), (int64_t)mt.roots.size(), &D.mesh_root))) return fail(rc);
+	}
 	{
 		static_assert(sizeof(rt_tri) == sizeof(rt_bvh_node) && sizeof(rt_bvh_node) == 64, "treelet slots are 64 B");
 		std::vector<rt_bvh_node> treelets;

@@ -126,6 +126,7 @@ __device__ __forceinline__ void boxNormal(const float* b, f3 hp, f3& n) {   // n
 }
 
 // Everything a kernel needs to know about the scene; passed by value (kernel arguments), pointers are HBM.
+#define RT_MESH_STACK 40   /* meshHit's stack: depth of a median-split tree over a mesh's triangles (checked at upload) */
 struct DevScene {
 	const rt_plane* planes;
 	const rt_sphere* spheres;
@@ -142,6 +143,9 @@ struct DevScene {
 	const uint8_t* texels;
 	const rt_bvh_node* nodes;
 	const uint32_t* leaf_prims;
+	const rt_bvh_node* mesh_nodes;     // per-mesh trees for Mesh::rayhit (meshHit); device-only, built at upload
+	const int32_t* mesh_order;         // their leaves: offsets into a mesh's triangles
+	const int32_t* mesh_root;          // per mesh: root node, or -1 = scan the triangles
 	const float4* treelets;            // the same tree cut into 1 KB treelets of up to 15 nodes (rt_kernels.h), device-only
 	int32_t treelet_root;              // 0 (slot 0 of treelet 0) or, for a one-leaf tree, the leaf reference
 	uint32_t treelet_root_aux;
@@ -154,12 +158,54 @@ struct DevScene {
 };
 
 // ---- Mesh::rayhit, objects.cpp:286-304 (linear scan in scene order; first of equal t wins) ----
-__device__ inline float meshHit(const DevScene& S, const rt_mesh& m, f3 e, f3 d, bool exitHit, f3& nrm) {
+// The result is a pure function of the triangles' own hit tests (the nearest positive t, lowest index among equals), so
+// for a mesh of some size the scan is replaced by a walk of a tree over its triangles whose boxes are conservative
+// (inflated at build time; a test too close to call counts as a hit): it skips only triangles that cannot be hit
+// nearer than the best so far.  SURVEY.md section 8f-3: without it a refractive mesh costs O(triangles) per bounce.
+__device__ __forceinline__ bool meshBoxMayHit(const float* b, f3 e, f3 inv, float tlimit) {
+	const float x0 = (b[0] - e.x) * inv.x, x1 = (b[1] - e.x) * inv.x;
+	const float y0 = (b[2] - e.y) * inv.y, y1 = (b[3] - e.y) * inv.y;
+	const float z0 = (b[4] - e.z) * inv.z, z1 = (b[5] - e.z) * inv.z;
+	const float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+	const float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+	const float u = fminf(hi, tlimit);
+	const float m = 1e-6f * (fabsf(lo) + fabsf(u)) + 1e-30f;
+	return !(u - lo < -m || hi < -1e-30f);   // not certainly missed / behind / beyond the best hit (NaN: visit)
+}
+__device__ inline float meshHit(const DevScene& S, int meshIndex, f3 e, f3 d, bool exitHit, f3& nrm) {
+	const rt_mesh m = S.meshes[meshIndex];
+	const rt_tri* tris = S.mesh_tris + m.tri_first;
 	float t_min = RT_MAX_T;
-	for (int i = 0; i < m.tri_count; i++) {
-		const rt_tri* tr = S.mesh_tris + m.tri_first + i;
-		float t = triHit(tr, e, d, exitHit);
-		if (t > 0.0f && t < t_min) { nrm = ld3(tr->n); t_min = t; }
+	const int32_t root = S.mesh_root[meshIndex];
+	const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	const bool finite = fabsf(inv.x) <= 3.0e38f && fabsf(inv.y) <= 3.0e38f && fabsf(inv.z) <= 3.0e38f;
+	if (root < 0 || !finite) {   // small mesh, or a ray parallel to an axis (0 * inf in the slab test): the reference's scan
+		for (int i = 0; i < m.tri_count; i++) {
+			float t = triHit(tris + i, e, d, exitHit);
+			if (t > 0.0f && t < t_min) { nrm = ld3(tris[i].n); t_min = t; }
+		}
+		return t_min == RT_MAX_T ? 0.0f : t_min;
+	}
+	int32_t stack[RT_MESH_STACK];
+	int sp = 0, best = 0x7fffffff;
+	int32_t cur = root;
+	for (;;) {
+		const rt_bvh_node* n = S.mesh_nodes + cur;
+		int32_t next = -1;
+		for (int k = 0; k < 2; k++) {
+			if (!meshBoxMayHit(n->box[k], e, inv, t_min)) continue;
+			const int32_t c = n->child[k];
+			if (c >= 0) { if (next < 0) next = c; else if (sp < RT_MESH_STACK) stack[sp++] = c; continue; }
+			const int32_t* order = S.mesh_order + ~c;
+			for (int j = 0; j < n->count[k]; j++) {
+				const int i = order[j];
+				const float t = triHit(tris + i, e, d, exitHit);
+				if (t > 0.0f && (t < t_min || (t == t_min && i < best))) { nrm = ld3(tris[i].n); t_min = t; best = i; }
+			}
+		}
+		if (next >= 0) cur = next;
+		else if (sp > 0) cur = stack[--sp];
+		else break;
 	}
 	return t_min == RT_MAX_T ? 0.0f : t_min;
 }
@@ -189,7 +235,7 @@ __device__ inline float csgLeafHit(const DevScene& S, const rt_csg_node& nd, f3 
 		return t;
 	}
 	f3 n = mk3(0, 0, 0);
-	float t = meshHit(S, S.meshes[nd.mesh], e, d, exitHit, n);
+	float t = meshHit(S, nd.mesh, e, d, exitHit, n);
 	if (nrm) *nrm = n;
 	return t;
 }

@@ -818,7 +818,7 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 			outNormal = sphereNormal(S, s, hp);
 		} else if (type == RT_PRIM_TRI) {
 			f3 nrm = outNormal;
-			const float t = meshHit(S, S.meshes[S.tris[ix].mesh], currentPoint, innerVector, true, nrm);
+			const float t = meshHit(S, S.tris[ix].mesh, currentPoint, innerVector, true, nrm);
 			if (t > 0.0f) hp = currentPoint + t * innerVector;
 			outNormal = nrm;
 		} else if (type == RT_PRIM_BOX) {

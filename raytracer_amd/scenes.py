@@ -234,3 +234,46 @@ def c5_scene(out_dir, grid=1581, binary=None):
     with open(path, "w") as f:
         json.dump(scene, f)
     return path
+
+
+def icosphere(subdiv, centre=(0.0, 0.0, 0.0), radius=1.0):
+    """Triangles [20 * 4^subdiv, 3, 3] of a subdivided icosahedron, wound so that normals point outwards."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], np.float64)
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    tris = np.array([[v[a], v[b], v[c]] for a, b, c in f])
+    for _ in range(subdiv):
+        a, b, c = tris[:, 0], tris[:, 1], tris[:, 2]
+        ab, bc, ca = (a + b) / 2, (b + c) / 2, (c + a) / 2
+        tris = np.concatenate([np.stack([a, ab, ca], 1), np.stack([b, bc, ab], 1), np.stack([c, ca, bc], 1), np.stack([ab, bc, ca], 1)])
+    tris = tris / np.linalg.norm(tris, axis=2, keepdims=True)
+    n = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 1])
+    flip = (n * tris.mean(axis=1)).sum(axis=1) < 0
+    tris[flip] = tris[flip][:, ::-1]
+    return (tris * radius + np.array(centre)).astype(np.float32)
+
+
+def mesh_scene(out_dir, subdiv=3):
+    """Meshes that are asked for hits on their own (Mesh::rayhit): a refractive icosphere (20 * 4^subdiv triangles) and a
+    CSG difference whose first operand is a mesh -- the cases SURVEY.md section 8f-3 names."""
+    os.makedirs(out_dir, exist_ok=True)
+    glass = {"type": "mesh", "material": {"ambient": [0.05, 0.05, 0.08], "diffuse": [0.2, 0.2, 0.3], "specular": [0.6, 0.6, 0.6], "shininess": 40.0,
+                                          "transmissive": [0.7, 0.7, 0.7], "refraction": 1.3}}
+    glass.update(_mesh_json(icosphere(subdiv, (-0.9, 0.0, -4.0), 0.8)))
+    csg_mesh = {"type": "mesh"}
+    csg_mesh.update(_mesh_json(icosphere(max(subdiv - 1, 0), (1.0, -0.1, -4.5), 0.8)))
+    carved = {"type": "csgobject", "material": {"ambient": [0.1, 0.05, 0.05], "diffuse": [0.8, 0.4, 0.3], "specular": [0.3, 0.3, 0.3], "shininess": 15.0},
+              "operation": "difference", "first": csg_mesh, "second": {"type": "sphere", "position": [1.3, 0.2, -3.9], "radius": 0.55}}
+    scene = {"camera": {"field": 60, "background": [0.1, 0.15, 0.25]},
+             "objects": [glass, carved,
+                         {"type": "plane", "position": [0, -1.0, 0], "normal": [0, 1, 0], "material": {"ambient": [0.1, 0.1, 0.1], "diffuse": [0.5, 0.5, 0.45]}},
+                         {"type": "sphere", "radius": 0.4, "position": [-0.6, -0.3, -6.0], "material": {"ambient": [0.1, 0.1, 0.0], "diffuse": [0.9, 0.8, 0.2]}}],
+             "lights": [{"type": "ambient", "color": [0.3, 0.3, 0.3]},
+                        {"type": "point", "color": [0.8, 0.8, 0.75], "position": [2.0, 4.0, -1.0]},
+                        {"type": "directional", "color": [0.3, 0.3, 0.35], "direction": [0.3, -1.0, -0.4]}]}
+    path = os.path.join(out_dir, f"mesh_{subdiv}.json")
+    with open(path, "w") as f:
+        json.dump(scene, f)
+    return path

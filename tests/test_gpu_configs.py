@@ -182,3 +182,25 @@ def test_c5_full_size_from_a_mesh_file(tmp_path):
     frame = sc.render(W4, H4, camera=cam4).reshape(-1, 3)[pick]
     assert np.abs(rgb8(frame).astype(int) - rgb8(o["rgb"]).astype(int)).max() <= 1
     sc.close()
+
+
+def test_meshes_asked_for_hits_on_their_own(tmp_path):
+    # Mesh::rayhit through the per-mesh tree: a refractive 1280-triangle icosphere (exit search of transmitRay, internal
+    # reflections) and a CSG difference with a 320-triangle mesh operand, against the oracle's linear scan
+    flat = rt.FlatScene.from_json(scenes.mesh_scene(str(tmp_path), subdiv=3))
+    assert flat.info.n_mesh_tris == 1280 + 320
+    sc = rt.Scene(flat, 0)
+    W, H = 320, 180
+    cam = rt.Camera(flat.fov, W, H)
+    s = primary_targets_np(cam, W, H)
+    e = np.zeros((W * H, 3), np.float32)
+    r = sc.trace_batch(e, s)
+    o = oracle.trace_batch(flat, e, s, seed=1, threads=8)
+    assert np.array_equal(r["id"], o["id"]) and np.array_equal(bits(r["t"]), bits(o["t"]))
+    assert sc.last_stats["rays_nearest"] == o["rays_nearest"] and sc.last_stats["rays_shadow"] == o["rays_shadow"]
+    d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(o["rgb"]).astype(int)).max(axis=1)
+    assert (d8 > 1).mean() < 1e-3, f"{(d8 > 1).sum()} pixels differ by more than 1/255"
+    assert len(np.unique(r["id"][r["hit"] != 0])) >= 4          # glass, carved mesh, floor, sphere all seen
+    img = sc.render(W, H, camera=cam)
+    assert np.abs(rgb8(img.reshape(-1, 3)).astype(int) - rgb8(o["rgb"]).astype(int)).max(axis=1).mean() < 0.01
+    sc.close()

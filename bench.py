@@ -55,11 +55,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box: RT_BENCH_REHEARSAL=1 puts every rank on device 0 and gathers through the host over gloo
+    rehearsal = os.environ.get("RT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}; launch N > 1 through torch.distributed.run", file=sys.stderr)
@@ -93,7 +100,11 @@ def main():
     def assemble(buf):
         # tiles -> rank 0 (RCCL gather over xGMI; point-to-point when the tile counts are ragged), then de-interleave
         scene.tiles_pack(buf.data_ptr(), packed.data_ptr(), W, H, rank, world, stream=stream)
-        bufs = rd.gather_packed(packed, sizes, rank, world, bufs=recv)
+        if rehearsal:
+            host = rd.gather_packed(packed.cpu(), sizes, rank, world)
+            bufs = [h.to(dev) for h in host] if rank == 0 else None
+        else:
+            bufs = rd.gather_packed(packed, sizes, rank, world, bufs=recv)
         if rank == 0:
             for r in range(1, world):
                 scene.tiles_unpack(bufs[r].data_ptr(), buf.data_ptr(), W, H, r, world, stream=stream)
@@ -144,10 +155,11 @@ def main():
     barrier()
     latency_ms = (time.perf_counter() - t1) / 5 * 1e3
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        cdev = "cpu" if rehearsal else dev
+        tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        rr = torch.tensor([rays], device=dev, dtype=torch.int64)
+        rr = torch.tensor([rays], device=cdev, dtype=torch.int64)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         rays = int(rr.item())
 

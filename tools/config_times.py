@@ -22,8 +22,12 @@ def run(name, path, W, H, aa=(1, 1), max_depth=16, eye=(0, 0, 0), rot_x=0.0, rep
     print(f"{name}: load {t_load:.1f} s, {dt * 1e3:.2f} ms/frame, {rays / 1e6:.1f} Mrays ({st['rays_nearest'] / 1e6:.1f} nearest), {rays / dt / 1e6:.0f} Mrays/s, levels {st['levels']}, splits {st['batch_splits']}", flush=True)
     sc.close()
 
+only = os.environ.get("CONFIG", "")
 with tempfile.TemporaryDirectory() as tmp:
+  if only in ("", "C3"):
     run("C3 csg 1080p depth5", scenes.c3_scene(tmp), 1920, 1080, max_depth=5, eye=(0, 1.0, 2.0), rot_x=-0.25)
+  if only in ("", "C4"):
     run("C4 area 64 1080p", scenes.c4_scene(tmp, 64), 1920, 1080)
-    g = int(os.environ.get("C5_GRID", "500"))
+  g = int(os.environ.get("C5_GRID", "500"))
+  if only in ("", "C5"):
     run(f"C5 grid {g} 4K 2x2", scenes.c5_scene(tmp, g), 3840, 2160, aa=(2, 2), eye=(0, 1.5, 1.0), rot_x=-0.3, reps=2)

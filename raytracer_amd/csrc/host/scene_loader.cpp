@@ -18,6 +18,10 @@
 #include "host_internal.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <future>
+#include <memory>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -233,14 +237,20 @@ struct Loader {
 		return b;
 	}
 
-	// Returns the (child, count) reference of the subtree over `objs` whose box is `box`.
-	void buildNode(std::vector<int>& objs, const Box6& box, int depth, int32_t& childOut, int32_t& countOut) {
+	// The reference's build (bvh.cpp:37-70) in two steps: the splits -- each node sorts its own object list, so sibling
+	// subtrees are independent and the top levels are built on separate threads (the sorts are where the time of a
+	// 5 M-triangle scene goes; every sort sees exactly the list it sees in the reference, so the tree is the same) --
+	// and then the flattening into pre-order nodes and leaf-order primitives, which is sequential.
+	struct TreeNode {
+		Box6 lb, rb;
+		std::unique_ptr<TreeNode> l, r;
+		std::vector<int> objs;   // leaf contents (leaf iff l == nullptr)
+	};
+	std::unique_ptr<TreeNode> splitNode(std::vector<int>& objs, const Box6& box, int depth) const {
+		std::unique_ptr<TreeNode> t(new TreeNode());
 		if (objs.size() <= 2 || depth >= RT_MAX_BVH_DEPTH) {   // bvh.cpp:39
-			childOut = ~(int32_t)S->leaf_prims.size();
-			countOut = (int32_t)objs.size();
-			for (int oi : objs) emitLeafPrim(bvhObjs[oi]);
-			S->leaf_prims.back() |= RT_PRIM_LAST;   // device leaf loops run until this flag instead of carrying a count
-			return;
+			t->objs.swap(objs);
+			return t;
 		}
 		float lengthX = box.b[1] - box.b[0], lengthY = box.b[3] - box.b[2], lengthZ = box.b[5] - box.b[4];
 		int axis = (lengthX >= lengthY && lengthX >= lengthZ) ? 0 : (lengthY >= lengthZ ? 1 : 2);   // bvh.cpp:48-56
@@ -249,14 +259,33 @@ struct Loader {
 		std::vector<int> left(objs.begin(), objs.begin() + objs.size() / 2);
 		std::vector<int> right(objs.begin() + objs.size() / 2, objs.end());
 		std::vector<int>().swap(objs);   // the reference keeps the parent's list alive; we do not need it
-		Box6 lb = unionBox(all, left), rb = unionBox(all, right);
+		t->lb = unionBox(all, left); t->rb = unionBox(all, right);
+		if (depth < 4 && left.size() + right.size() > 20000) {
+			auto fut = std::async(std::launch::async, [&] { return splitNode(left, t->lb, depth + 1); });
+			t->r = splitNode(right, t->rb, depth + 1);
+			t->l = fut.get();
+		} else {
+			t->l = splitNode(left, t->lb, depth + 1);
+			t->r = splitNode(right, t->rb, depth + 1);
+		}
+		return t;
+	}
+	// Returns the (child, count) reference of the subtree `t`.
+	void flattenNode(const TreeNode& t, int32_t& childOut, int32_t& countOut) {
+		if (!t.l) {
+			childOut = ~(int32_t)S->leaf_prims.size();
+			countOut = (int32_t)t.objs.size();
+			for (int oi : t.objs) emitLeafPrim(bvhObjs[oi]);
+			S->leaf_prims.back() |= RT_PRIM_LAST;   // device leaf loops run until this flag instead of carrying a count
+			return;
+		}
 		int32_t self = (int32_t)S->bvh_nodes.size();
 		S->bvh_nodes.push_back(rt_bvh_node());
 		int32_t c0, n0, c1, n1;
-		buildNode(left, lb, depth + 1, c0, n0);
-		buildNode(right, rb, depth + 1, c1, n1);
+		flattenNode(*t.l, c0, n0);
+		flattenNode(*t.r, c1, n1);
 		rt_bvh_node& n = S->bvh_nodes[self];
-		memcpy(n.box[0], lb.b, sizeof lb.b); memcpy(n.box[1], rb.b, sizeof rb.b);
+		memcpy(n.box[0], t.lb.b, sizeof t.lb.b); memcpy(n.box[1], t.rb.b, sizeof t.rb.b);
 		n.child[0] = c0; n.child[1] = c1; n.count[0] = n0; n.count[1] = n1;
 		childOut = self; countOut = 0;
 	}
@@ -417,7 +446,13 @@ struct Loader {
 			for (size_t i = 0; i < all.size(); i++) all[i] = (int)i;
 			Box6 rootBox = unionBox(bvhObjs, all);
 			memcpy(V.root_box, rootBox.b, sizeof rootBox.b);
-			buildNode(all, rootBox, 0, V.root_child, V.root_count);
+			const bool timing = getenv("RT_LOAD_TIMING") != nullptr;
+			const auto t0 = std::chrono::steady_clock::now();
+			std::unique_ptr<TreeNode> tree = splitNode(all, rootBox, 0);
+			const auto t1 = std::chrono::steady_clock::now();
+			flattenNode(*tree, V.root_child, V.root_count);
+			const auto t2 = std::chrono::steady_clock::now();
+			if (timing) fprintf(stderr, "[load] bvh split %.2f s, flatten %.2f s\n", std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count());
 		}
 		S->link();
 	}

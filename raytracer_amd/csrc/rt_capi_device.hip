@@ -448,7 +448,7 @@ struct Run {
 
 	// Which traversal form a level uses.  Level 0 of a frame (and its shadow rays) is coherent by construction: 64
 	// consecutive queue slots are an 8x8 pixel block.  Deeper levels and caller-supplied rays are walked per lane.
-	int packetLevels = 1;
+	int packetLevels = (int)envU32("RT_PACKET_LEVELS", 1);
 	bool coherent(int level) const { return src.camera && level < packetLevels; }
 
 	int syncCounters() {
@@ -552,6 +552,7 @@ int finish(rt_scene* sc, rt_scene::Lane* ln, hipStream_t st, Run& run, rt_stats*
 		std::vector<RtCounters> c(1);
 		HIPCHK(hipMemcpy(c.data(), ln->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost));
 		if (FILE* f = fopen(path, "wb")) { fwrite(c[0].trace, sizeof c[0].trace, 1, f); fwrite(c[0].waveLog, sizeof c[0].waveLog, 1, f); fclose(f); }
+		for (int k = 0; k < 2; k++) { fprintf(stderr, "[lane histogram %s]", k ? "shadow" : "nearest"); for (int i = 0; i < 7; i++) fprintf(stderr, " %llu", c[0].laneHist[k][i]); fprintf(stderr, "\n"); }
 	}
 #endif
 	if (stats) *stats = run.stats;

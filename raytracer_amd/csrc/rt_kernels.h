@@ -73,6 +73,7 @@ struct RtCounters {
 	unsigned long long nodes_shadow, prims_shadow;     // ... and in the shadow kernels
 #if RT_PROF
 	unsigned long long trace[2][4][RT_TRACE_LEN];      // RT_PROF builds: step traces of four waves of the two packet kernels
+	unsigned long long laneHist[2][8];                 // node steps by number of rays in the node: 1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64
 	uint32_t waveLog[2][8192][8];                      // per wave: start, end (100 MHz wall clock), longest packet, packets; that packet's union steps, max / sum of per-ray nodes, rays
 #endif
 };

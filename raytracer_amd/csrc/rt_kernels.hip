@@ -369,12 +369,13 @@ __device__ __forceinline__ uint32_t waveCount() { return gridDim.x * (kBlock / 6
 // 2 rays loaded + init done, 3 node step start (value = slot), 4 treelet staged, 5 node read + classified,
 // 6 step end, 7 leaf start (value = count), 8 leaf end, 9 walk done, 10 next packet fetched, 11 results stored
 #if RT_PROF
-struct Tracer { unsigned long long* buf; uint32_t n; bool on; };
+struct Tracer { unsigned long long* buf; uint32_t n; bool on; uint32_t hist[8]; };
 __device__ __forceinline__ Tracer tracerFor(RtCounters* ctr, int kernel) {
 	Tracer tr;
 	const uint32_t w = waveNumber();
 	const int slot = w == 100u ? 0 : w == 1000u ? 1 : w == 2000u ? 2 : w == 3000u ? 3 : -1;
 	tr.on = slot >= 0; tr.n = 0; tr.buf = ctr->trace[kernel][slot < 0 ? 0 : slot];
+	for (int i = 0; i < 8; i++) tr.hist[i] = 0;
 	return tr;
 }
 #define TR_DECL(kernel) Tracer tr = tracerFor(ctr, kernel); Tracer* trp = &tr; \
@@ -383,7 +384,7 @@ __device__ __forceinline__ Tracer tracerFor(RtCounters* ctr, int kernel) {
 		uint32_t _c = (alive) ? (uint32_t)(T).cntNodes : 0u, _m = _c, _s = _c; \
 		for (int _o = 32; _o; _o >>= 1) { const uint32_t _a = __shfl_xor(_m, _o), _b = __shfl_xor(_s, _o); _m = _a > _m ? _a : _m; _s += _b; } \
 		wlSteps = __builtin_amdgcn_readfirstlane((T).steps); wlLaneMax = _m; wlLaneSum = _s; wlLanes = (uint32_t)__popcll(__ballot(alive)); } wlLast = _n; wlN++; } while (0)
-#define WL_END() do { if (__lane_id() == 0 && waveNumber() < 8192u) { uint32_t* _w = ctr->waveLog[wlK][waveNumber()]; _w[0] = wlStart; _w[1] = (uint32_t)wall_clock64(); _w[2] = wlMax; _w[3] = wlN; \
+#define WL_END() do { if (__lane_id() == 0) for (int _i = 0; _i < 7; _i++) atomicAdd(&ctr->laneHist[wlK][_i], (unsigned long long)tr.hist[_i]); if (__lane_id() == 0 && waveNumber() < 8192u) { uint32_t* _w = ctr->waveLog[wlK][waveNumber()]; _w[0] = wlStart; _w[1] = (uint32_t)wall_clock64(); _w[2] = wlMax; _w[3] = wlN; \
 		_w[4] = wlSteps; _w[5] = wlLaneMax; _w[6] = wlLaneSum; _w[7] = wlLanes; } } while (0)
 #define TR(tag, val) do { if (trp->on) { const unsigned long long _t = __builtin_readcyclecounter(); \
 	if (__lane_id() == 0 && trp->n < RT_TRACE_LEN) trp->buf[trp->n] = ((unsigned long long)(tag) << 56) | ((unsigned long long)((val) & 0xffffu) << 40) | (_t & 0xffffffffffull); trp->n++; } } while (0)
@@ -473,6 +474,7 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			TR(3, node & 15);
 #if RT_PROF
 			T.steps++;
+			{ const int act = __popcll(__ballot(inSub)); const int b = act <= 2 ? 0 : act <= 4 ? 1 : act <= 8 ? 2 : act <= 16 ? 3 : act <= 32 ? 4 : act <= 48 ? 5 : 6; if (trp) trp->hist[b]++; }
 #endif
 			const bool cons = ((uint32_t)node & RT_TREELET_CONS) != 0u;   // a node of a sub-tree under a fat leaf: conservative box tests
 			const int32_t nidx = (int32_t)((uint32_t)node & (RT_TREELET_CONS - 1u));

@@ -658,7 +658,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	*out = nullptr;
 	if (int rc = rt::validate_flat_scene(s)) return rc;
 	const int depth = treeDepth(s);
-	if (depth > RT_STACK_DEPTH) { rt::set_error("BVH deeper than the device traversal stack (RT_STACK_DEPTH)"); return RT_ELIMIT; }
+	if (depth > RT_MAX_TREE_DEPTH) { rt::set_error("BVH deeper than RT_MAX_TREE_DEPTH"); return RT_ELIMIT; }
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { rt::set_error("no HIP device available: the MI355X path has no CPU fallback"); return RT_EHIP; }
 	if (device < 0 || device >= ndev) { rt::set_error("rt_scene_upload: no such device"); return RT_EINVAL; }
@@ -684,7 +684,6 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	if ((rc = sc->upload(s->lights, s->n_lights, &D.lights))) return fail(rc);
 	if ((rc = sc->upload(s->textures, s->n_textures, &D.textures))) return fail(rc);
 	if ((rc = sc->upload(s->texels, s->n_texel_bytes, &D.texels))) return fail(rc);
-	if ((rc = sc->upload(s->bvh_nodes, s->n_bvh_nodes, &D.nodes))) return fail(rc);
 	if ((rc = sc->upload(s->leaf_prims, s->n_leaf_prims, &D.leaf_prims))) return fail(rc);
 	{
 		MeshTrees mt;

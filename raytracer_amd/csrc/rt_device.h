@@ -141,7 +141,6 @@ struct DevScene {
 	const rt_light* lights;
 	const rt_texture* textures;
 	const uint8_t* texels;
-	const rt_bvh_node* nodes;
 	const uint32_t* leaf_prims;
 	const rt_bvh_node* mesh_nodes;     // per-mesh trees for Mesh::rayhit (meshHit); device-only, built at upload
 	const int32_t* mesh_order;         // their leaves: offsets into a mesh's triangles

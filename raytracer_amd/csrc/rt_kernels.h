@@ -15,9 +15,10 @@
 #ifndef RT_PACKET_WAVES_PER_SIMD
 #define RT_PACKET_WAVES_PER_SIMD 5   /* register budget of the packet kernels: 512 / 5 -> 96 VGPRs (6 and 8 spill and are slower) */
 #endif
-#define RT_STACK_DEPTH 20     /* per-lane traversal stack entries in LDS (20 x 256 x 4 B = 20 KB per workgroup);
-                                 a nearer-child-first walk of a binary tree needs at most its depth, and the
-                                 reference's build stops at depth 16 (bvh.h:6); checked at upload */
+#define RT_MAX_TREE_DEPTH 20   /* deepest reference tree accepted at upload (the reference's build stops at 16, bvh.h:6) */
+#define RT_STACK_DEPTH 32     /* traversal stack entries: per lane in LDS for the per-lane walk (32 x 256 x 4 B = 32 KB per
+                                 workgroup), per wave for packets.  A nearer-child-first walk of a binary tree needs at most
+                                 its depth: the reference tree plus the sub-trees under fat leaves; checked at upload */
 
 // Treelets (packet traversal): the BVH regrouped into records of 16 slots x 64 B = 1 KB.  A NODE slot has the layout
 // of rt_bvh_node (two child boxes, two child references) with count[] replaced by aux[]:
@@ -42,7 +43,7 @@
 #define RT_TREELET_EMBED_MAX 8u           /* longest run that is embedded; longer all-triangle leaves get a sub-tree */
 #define RT_TREELET_SUBLEAF_MAX 4u         /* triangles per leaf of such a sub-tree */
 #define RT_TREELET_CONS (1u << 29)        /* flag on a child reference: the node belongs to a sub-tree, its box tests are conservative */
-#define RT_PACKET_STACK_DEPTH 40          /* wave stack entries: reference depth <= RT_STACK_DEPTH plus the sub-trees */
+#define RT_PACKET_STACK_DEPTH RT_STACK_DEPTH   /* wave stack entries */
 #define RT_PACKET_STACK_BYTES (RT_PACKET_STACK_DEPTH * 16)
 // LDS of a packet kernel's workgroup: the root treelet once (every packet starts there; fetched when the workgroup
 // starts), then per wave one 1 KB buffer per deeper treelet level, one more when the scene has external runs to stage,

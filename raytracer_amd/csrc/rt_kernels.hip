@@ -203,6 +203,7 @@ struct Trav {
 	f3 e, d, inv;
 	bool special;   // 1/d is not finite on some axis (boxClassify)
 	int32_t cur;
+	uint32_t aux, base;   // per-lane walk, when cur is a leaf: its aux word and the treelet it hangs in
 	int sp;
 	float tmin; uint32_t best, bestKey, bestTag;   // nearest
 	f3 shadow; float len; bool lit;                 // any-hit
@@ -235,30 +236,69 @@ __device__ __forceinline__ void travInit(const DevScene& S, Trav& T, f3 e, f3 d)
 	if (S.root_child < 0 && S.root_count == 0) return;
 	const float tr = boxIntersect(S.root_box, e, d, false);   // the root's own box (bvh.cpp:97-100 / 131-134), exact
 	if (tr < 0 || tr > (ANYHIT ? 1.0f : T.tmin)) return;
-	T.cur = S.root_child;
+	T.cur = S.treelet_root;   // slot 0 of treelet 0, or the one leaf of a one-leaf tree
+	T.aux = S.treelet_root_aux; T.base = 0;
 }
 
+// bvh.cpp:109-118 / 145-157 for one candidate hit at parameter t
+template <bool ANYHIT>
+__device__ __forceinline__ bool travAccept(const DevScene& S, Trav& T, float t, uint32_t ref, uint32_t tag, uint32_t key, int mat) {
+	if (!ANYHIT) {
+		if ((double)t > 1e-5 && (t < T.tmin || (t == T.tmin && key < T.bestKey))) { T.best = ref; T.bestTag = tag; T.tmin = t; T.bestKey = key; }
+	} else if (t < 1.0f && (double)(t * T.len) > 1e-5) {
+		const float* kt = S.materials[mat].transmissive;
+		if (!isZero3(kt)) T.shadow = T.shadow * ld3(kt);
+		else { T.lit = false; return false; }
+	}
+	return true;
+}
+
+// The per-lane walk runs over the same tree as the packets (the treelet records, rt_kernels.h, read from memory one
+// 64 B node at a time), so it too finds the triangles of small leaves next to their nodes and walks the conservative
+// sub-trees of fat leaves.
 template <bool ANYHIT, bool CSG, bool COUNT>
 __device__ __forceinline__ void travLeaf(const DevScene& S, Trav& T) {
-	int32_t at = ~T.cur;
-	bool more = true;
-	while (more) {
-		const uint32_t entry = S.leaf_prims[at];
-		const uint32_t ref = entry & ~RT_PRIM_LAST;
-		more = (entry & RT_PRIM_LAST) == 0;
-		uint32_t tag = 0;
-		const float t = primHit<CSG>(S, ref, T.e, T.d, tag);
-		if (COUNT) T.cntPrims++;
-		if (!ANYHIT) {   // bvh.cpp:109-118
-			const uint32_t key = (uint32_t)at + 1u;
-			if ((double)t > 1e-5 && (t < T.tmin || (t == T.tmin && key < T.bestKey))) { T.best = ref; T.bestTag = tag; T.tmin = t; T.bestKey = key; }
-		} else if (t < 1.0f && (double)(t * T.len) > 1e-5) {   // bvh.cpp:145-157
-			const float* kt = S.materials[primMaterial(S, ref)].transmissive;
-			if (!isZero3(kt)) T.shadow = T.shadow * ld3(kt);
-			else { T.lit = false; more = false; }
+	const uint32_t info = T.aux;
+	if (info == RT_TREELET_NO_RUN) {   // any primitives: through leaf_prims
+		int32_t at = ~T.cur;
+		bool more = true;
+		while (more) {
+			const uint32_t entry = S.leaf_prims[at];
+			const uint32_t ref = entry & ~RT_PRIM_LAST;
+			more = (entry & RT_PRIM_LAST) == 0;
+			uint32_t tag = 0;
+			const float t = primHit<CSG>(S, ref, T.e, T.d, tag);
+			if (COUNT) T.cntPrims++;
+			if (!travAccept<ANYHIT>(S, T, t, ref, tag, (uint32_t)at + 1u, ANYHIT ? primMaterial(S, ref) : 0)) more = false;
+			at++;
 		}
-		at++;
+		return;
 	}
+	const bool longRun = (info >> 26) == 0u;
+	const uint32_t count = longRun ? info : info >> 26;
+	const bool embedded = !longRun && (info & RT_TREELET_EMBED);
+	const uint32_t first = embedded ? 0u : longRun ? (uint32_t)~T.cur : info & (RT_TREELET_EMBED - 1u);
+	const rt_tri* tris = embedded ? reinterpret_cast<const rt_tri*>(S.treelets) + (size_t)T.base * RT_TREELET_SLOTS + (info & 15u) : S.tris + first;
+	for (uint32_t k = 0; k < count; k++) {
+		const float4* q = reinterpret_cast<const float4*>(tris + k);
+		const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+		const float t = triHit(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), T.e, T.d, false);
+		if (COUNT) T.cntPrims++;
+		const uint32_t index = embedded ? __float_as_uint(d.z) : first + k;
+		const uint32_t key = embedded ? __float_as_uint(d.w) : (uint32_t)~T.cur + 1u + k;
+		if (!travAccept<ANYHIT>(S, T, t, RT_PRIM_REF(RT_PRIM_TRI, index), 0u, key, __float_as_int(d.y))) break;
+	}
+}
+
+// Stack entries: an inner node's reference (>= 0), or -(2 * parent + k) - 1 for leaf child k of node `parent` (its
+// reference and aux word are read from the parent again when it is popped).
+__device__ __forceinline__ void travPop(const DevScene& S, int32_t (*stack)[kBlock], Trav& T) {
+	if (T.sp == 0) { T.cur = kEmpty; return; }
+	const int32_t v = stack[--T.sp][threadIdx.x];
+	if (v >= 0) { T.cur = v; return; }
+	const uint32_t code = (uint32_t)(-(v + 1));
+	const rt_bvh_node* n = reinterpret_cast<const rt_bvh_node*>(S.treelets) + (code >> 1);
+	T.cur = n->child[code & 1u]; T.aux = (uint32_t)n->count[code & 1u]; T.base = code >> 5;
 }
 
 // One round: descend to the next leaf, test it, pick what comes next.  Returns with T.cur == kEmpty when the query is over.
@@ -266,28 +306,36 @@ template <bool ANYHIT, bool CSG, bool COUNT>
 __device__ __forceinline__ void travRound(const DevScene& S, int32_t (*stack)[kBlock], Trav& T) {
 	const int tid = threadIdx.x;
 	while (T.cur >= 0 && T.cur != kEmpty) {
-		const NodeRegs N = loadNode(S.nodes + T.cur);
+		const bool cons = ((uint32_t)T.cur & RT_TREELET_CONS) != 0u;
+		const uint32_t nidx = (uint32_t)T.cur & (RT_TREELET_CONS - 1u);
+		const rt_bvh_node* np = reinterpret_cast<const rt_bvh_node*>(S.treelets) + nidx;
+		const NodeRegs N = loadNode(np);
+		const uint32_t x0 = (uint32_t)np->count[0], x1 = (uint32_t)np->count[1];
 		if (COUNT) T.cntNodes++;
 		const float tlimit = ANYHIT ? 1.0f : T.tmin;
 		float t0, t1;
 		int k0 = boxClassify(N.b0, T.e, T.inv, T.special, tlimit, t0);
 		int k1 = boxClassify(N.b1, T.e, T.inv, T.special, tlimit, t1);
-		if (k0 == 2 || k1 == 2) {   // too close to call with the multiply: the reference's own arithmetic decides
-			if (k0 == 2) { const float t = boxIntersect(N.b0, T.e, T.d, false); k0 = !(t < 0 || t > tlimit); }
-			if (k1 == 2) { const float t = boxIntersect(N.b1, T.e, T.d, false); k1 = !(t < 0 || t > tlimit); }
+		if (k0 == 2 || k1 == 2) {   // too close to call with the multiply: a visit in a conservative sub-tree, else the reference's own arithmetic decides
+			if (k0 == 2) { if (cons) k0 = 1; else { const float t = boxIntersect(N.b0, T.e, T.d, false); k0 = !(t < 0 || t > tlimit); } }
+			if (k1 == 2) { if (cons) k1 = 1; else { const float t = boxIntersect(N.b1, T.e, T.d, false); k1 = !(t < 0 || t > tlimit); } }
 		}
+		int take = -1;   // the child to continue with
 		if (k0 && k1) {
 			const bool swap = !ANYHIT && t1 < t0;
-			if (T.sp < kStack) stack[T.sp++][tid] = swap ? N.c0 : N.c1;
-			T.cur = swap ? N.c1 : N.c0;
-		} else if (k0) T.cur = N.c0;
-		else if (k1) T.cur = N.c1;
-		else T.cur = T.sp > 0 ? stack[--T.sp][tid] : kEmpty;
+			const int far = swap ? 0 : 1;
+			const int32_t cf = far ? N.c1 : N.c0;
+			if (T.sp < kStack) stack[T.sp++][tid] = cf >= 0 ? cf : -(int32_t)(2u * nidx + (uint32_t)far) - 1;
+			take = 1 - far;
+		} else if (k0) take = 0;
+		else if (k1) take = 1;
+		if (take < 0) travPop(S, stack, T);
+		else { T.cur = take ? N.c1 : N.c0; T.aux = take ? x1 : x0; T.base = nidx >> 4; }
 	}
 	if (T.cur != kEmpty) {   // a leaf
 		travLeaf<ANYHIT, CSG, COUNT>(S, T);
 		if (ANYHIT && !T.lit) { T.cur = kEmpty; T.sp = 0; }
-		else T.cur = T.sp > 0 ? stack[--T.sp][tid] : kEmpty;
+		else travPop(S, stack, T);
 	}
 }
 

@@ -39,6 +39,7 @@ struct rt_scene {
 	int device = 0;
 	DevScene dev{};
 	bool hasCsg = false;
+	bool hasTransmissive = false;   // some material transmits: k_shade queues requests for k_transmit
 	std::vector<void*> allocs;
 	// lights, split by how their shadow rays are generated
 	int32_t* pointLights = nullptr;
@@ -50,7 +51,7 @@ struct rt_scene {
 	// host thread: the kernels of a level have long tails (a few packets walk ten times the average), and with several
 	// independent shards in flight the tail of one kernel is filled by the kernels of the others.
 	struct Lane {
-		RtQueue ray[2]{}, hitq{}, surfq{};
+		RtQueue ray[2]{}, hitq{}, surfq{}, transq{};
 		RtCounters* ctr = nullptr;       // device
 		RtCounters* ctrHost = nullptr;   // pinned
 		hipEvent_t ev[6]{};              // 0,1 whole call; 2,3 nearest kernel; 4,5 shadow kernels
@@ -110,6 +111,7 @@ struct rt_scene {
 		if (int rc = allocQueue(ln.ray[1], RQ_COMPS)) return rc;
 		if (int rc = allocQueue(ln.hitq, HQ_COMPS)) return rc;
 		if (int rc = allocQueue(ln.surfq, SQ_COMPS)) return rc;
+		if (hasTransmissive) { if (int rc = allocQueue(ln.transq, TQ_COMPS)) return rc; }
 		void* p = nullptr;
 		HIPCHK(hipMalloc(&p, sizeof(RtCounters)));
 		allocs.push_back(p);
@@ -472,8 +474,9 @@ struct Run {
 			if (timeK) HIPCHK(hipEventRecord(ln->ev[2], st));
 			rtk_intersect(st, sc->dev, sc->hasCsg, count, coherent(level), sc->maxBlocks, ln->ray[cur], n, ln->hitq, ln->ctr);
 			if (timeK) HIPCHK(hipEventRecord(ln->ev[3], st));
-			rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, n, ln->ray[cur ^ 1], ln->surfq, ln->ctr, sc->accum, aaSq, maxDepth,
+			rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, n, ln->ray[cur ^ 1], ln->surfq, ln->transq, ln->ctr, sc->accum, aaSq, maxDepth,
 			          sc->shadowRaysPerSurface > 0, level == 0 ? src.outHit : nullptr, src.outId, src.outT);
+			if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, n, ln->ray[cur ^ 1], ln->ctr, sc->accum, aaSq, maxDepth);
 			if (int rc = syncCounters()) return rc;
 			if (timeK) {
 				float ms = 0;
@@ -636,6 +639,32 @@ void laneWorker(rt_scene* sc, int k) {
 	}
 }
 
+// The most intervals a step of any CSG program of the scene can hold (stacked lists together, or the list an operator
+// writes): a leaf gives at most 1, Union n1 + n2, Intersection n1 * n2 (csg.cpp:190-200 pairs every interval with every
+// interval), Difference n1 + n2.  Kernels that keep the lists in LDS size them by this; clamped to the capacity of
+// the general path, whose truncation then applies to both alike.
+int csgCapacity(const rt_flat_scene* s) {
+	long long need = 1;
+	for (int32_t c = 0; c < s->n_csgs; c++) {
+		std::vector<long long> stack;
+		long long total = 0;
+		for (int32_t k = 0; k < s->csgs[c].node_count; k++) {
+			const int kind = s->csg_nodes[s->csgs[c].node_first + k].kind;
+			if (kind >= RT_CSG_SPHERE) { stack.push_back(1); total += 1; }
+			else if (stack.size() >= 2) {
+				const long long n2 = stack.back(); stack.pop_back();
+				const long long n1 = stack.back(); stack.pop_back();
+				const long long n = std::min<long long>(kind == RT_CSG_INTERSECTION ? n1 * n2 : n1 + n2, 1 << 20);
+				need = std::max(need, n);
+				total += n - n1 - n2;
+				stack.push_back(n);
+			}
+			need = std::max(need, total);
+		}
+	}
+	return (int)std::min<long long>(need, RTD_CSG_CAP);
+}
+
 struct DevBuf {   // scoped device allocation
 	void* p = nullptr;
 	~DevBuf() { if (p) (void)hipFree(p); }
@@ -717,6 +746,13 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	memcpy(D.root_box, s->root_box, sizeof D.root_box);
 	memcpy(D.background, s->background, sizeof D.background);
 	sc->hasCsg = s->n_csgs > 0;
+	D.csg_cap = csgCapacity(s);
+	D.csg_nodes_max = 1;
+	for (int32_t i = 0; i < s->n_csgs; i++) D.csg_nodes_max = std::max(D.csg_nodes_max, s->csgs[i].node_count);
+	for (int32_t i = 0; i < s->n_materials; i++) {
+		const float* kt = s->materials[i].transmissive;
+		if (kt[0] != 0 || kt[1] != 0 || kt[2] != 0) sc->hasTransmissive = true;
+	}
 
 	std::vector<int32_t> pl;
 	for (int i = 0; i < s->n_lights; i++) {

@@ -150,6 +150,8 @@ struct DevScene {
 	uint32_t treelet_root_aux;
 	int32_t treelet_levels;            // treelets on the longest root-to-leaf path (sizes the packet kernels' LDS)
 	int32_t treelet_staging;           // some leaf is an external run (needs the staging buffer)
+	int32_t csg_cap;                   // intervals the largest CSG program of the scene can hold at any step (<= RTD_CSG_CAP)
+	int32_t csg_nodes_max;             // nodes of the longest CSG program
 	int32_t n_planes, n_lights;
 	int32_t root_child, root_count;
 	float root_box[6];
@@ -239,106 +241,226 @@ __device__ inline float csgLeafHit(const DevScene& S, const rt_csg_node& nd, f3 
 	return t;
 }
 
+// Working storage of one evaluation: the interval lists of the evaluation stack (`arena`), the list an operator is
+// producing (`tmp`).  CsgScratch keeps them in the lane's private (scratch) memory at
+// the full capacity; CsgLds in a slice of the workgroup's LDS sized for the scene's largest program (DevScene::csg_cap),
+// element i of thread t at [i * threads + t] -- an evaluation is a chain of dependent reads and writes of these lists,
+// and LDS answers in ~100 cycles where scratch memory takes an L2 round trip.
+// start[k] = arena offset of list k of the evaluation stack (start[sp] = end of the last one): 16 values of at most
+// RTD_CSG_CAP, kept as bytes of two registers -- every step of a program begins by reading two or three of them, and as
+// an indexed array they would sit in memory at the head of each step's dependency chain.  start[0] is always 0.
+struct CsgStarts {
+	unsigned long long lo = 0, hi = 0;
+	__device__ __forceinline__ int get(int i) const {
+		const int j = i - 1;
+		const unsigned long long w = j < 8 ? lo : hi;
+		return i == 0 ? 0 : (int)((w >> ((j & 7) * 8)) & 0xffull);
+	}
+	__device__ __forceinline__ void set(int i, int v) {   // i >= 1
+		const int j = i - 1, sh = (j & 7) * 8;
+		const unsigned long long m = ~(0xffull << sh), b = (unsigned long long)(uint32_t)v << sh;
+		if (j < 8) lo = (lo & m) | b; else hi = (hi & m) | b;
+	}
+};
+static_assert(RT_MAX_CSG_LEAVES <= 16 && 2 * RT_MAX_CSG_LEAVES <= 255, "CsgStarts holds 16 one-byte offsets");
+
+struct CsgScratch {
+	CsgIv arena_[RTD_CSG_CAP], tmp_[RTD_CSG_CAP];
+	__device__ __forceinline__ int cap() const { return RTD_CSG_CAP; }
+	__device__ __forceinline__ CsgIv& arena(int i) { return arena_[i]; }
+	__device__ __forceinline__ CsgIv& tmp(int i) { return tmp_[i]; }
+	__device__ __forceinline__ void loadProgram(const DevScene&, const rt_csg&) {}
+	__device__ __forceinline__ rt_csg_node node(const DevScene& S, const rt_csg& c, int k) const { return S.csg_nodes[c.node_first + k]; }
+};
+// ... and a copy of the object's program, fetched with all its loads in flight at once (loadProgram) instead of one
+// L2 round trip per node in the middle of the evaluation.
+struct CsgLds {
+	CsgIv* arena_; CsgIv* tmp_; float4* nodes_;   // this thread's element 0 of each
+	int threads, cap_;
+	__device__ __forceinline__ int cap() const { return cap_; }
+	__device__ __forceinline__ CsgIv& arena(int i) { return arena_[i * threads]; }
+	__device__ __forceinline__ CsgIv& tmp(int i) { return tmp_[i * threads]; }
+	__device__ __forceinline__ void loadProgram(const DevScene& S, const rt_csg& c) {
+		const float4* src = reinterpret_cast<const float4*>(S.csg_nodes + c.node_first);
+		for (int k = 0; k < c.node_count; k += 4) {
+			float4 v[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) v[j] = src[2 * k + (2 * k + j < 2 * c.node_count ? j : 0)];
+#pragma unroll
+			for (int j = 0; j < 8; j++) if (2 * k + j < 2 * c.node_count) nodes_[(2 * k + j) * threads] = v[j];
+		}
+	}
+	__device__ __forceinline__ rt_csg_node node(const DevScene&, const rt_csg&, int k) const {
+		const float4 a = nodes_[2 * k * threads], b = nodes_[(2 * k + 1) * threads];
+		rt_csg_node nd;
+		nd.kind = __float_as_int(a.x); nd.mesh = __float_as_int(a.y);
+		nd.f[0] = a.z; nd.f[1] = a.w; nd.f[2] = b.x; nd.f[3] = b.y; nd.f[4] = b.z; nd.f[5] = b.w;
+		return nd;
+	}
+};
+#define RTD_CSG_LDS_BYTES(threads, cap, nodes) ((size_t)(threads) * (2u * (size_t)(cap) * sizeof(CsgIv) + (size_t)(nodes) * sizeof(rt_csg_node)))
+__device__ __forceinline__ CsgLds csgLdsStore(void* lds, int threads, int thread, int cap) {
+	CsgLds st;
+	st.arena_ = (CsgIv*)lds + thread;
+	st.tmp_ = (CsgIv*)lds + (size_t)cap * threads + thread;
+	st.nodes_ = (float4*)((CsgIv*)lds + 2 * (size_t)cap * threads) + thread;
+	st.threads = threads; st.cap_ = cap;
+	return st;
+}
+
+// Both hits of a leaf at once (csg.cpp:99-111 asks rayhit for the entry and then for the exit): the two calls share the
+// slab divisions (box) or the discriminant, its root and the quotients (sphere), so evaluating them together halves the
+// work and gives the same two values.
+__device__ __forceinline__ void csgLeafHits(const DevScene& S, const rt_csg_node& nd, f3 e, f3 d, float& tn, float& tf) {
+	if (nd.kind == RT_CSG_SPHERE) {   // sphereHit(..., false) and sphereHit(..., true)
+		const f3 ec = e - mk3(nd.f[0], nd.f[1], nd.f[2]);
+		const float radius = nd.f[3];
+		const float dde = dot(d, ec);
+		const float dd = dot(d, d);
+		const double disc = (double)dde * (double)dde - (double)(dd * (dot(ec, ec) - radius * radius));
+		tn = tf = 0.0f;
+		if (disc < 0) return;
+		const double rest = (double)(dot(-d, ec) / dd);
+		const double q = sqrt(disc) / (double)dd;
+		const double t0 = rest - q, t1 = rest + q;
+		if (!(t0 < 0)) tn = (float)t0;
+		if (!(t1 < 0)) tf = (float)t1;
+		return;
+	}
+	if (nd.kind == RT_CSG_BOX) {   // boxHit(..., false) and boxHit(..., true)
+		float tnear = -RT_MAX_T, tfar = RT_MAX_T;
+		bool miss = false;
+		slab(nd.f[0], nd.f[1], e.x, d.x, tnear, tfar, miss);
+		slab(nd.f[2], nd.f[3], e.y, d.y, tnear, tfar, miss);
+		slab(nd.f[4], nd.f[5], e.z, d.z, tnear, tfar, miss);
+		tn = (miss || tnear < 0) ? 0.0f : tnear;
+		tf = (miss || tfar < 0) ? 0.0f : tfar;
+		return;
+	}
+	tn = csgLeafHit(S, nd, e, d, false, nullptr);
+	tf = csgLeafHit(S, nd, e, d, true, nullptr);
+}
+
 // Evaluates the object's post-order program for one ray; returns csgObject::rayhit's t (0 = no hit) and the tag of
-// the selected boundary.
-__device__ inline float csgEval(const DevScene& S, const rt_csg& c, f3 e, f3 d, bool exitHit, uint32_t& tagOut) {
-	CsgIv arena[RTD_CSG_CAP];
-	CsgIv tmp[RTD_CSG_CAP];
-	int start[RT_MAX_CSG_LEAVES + 1];   // start[k] = arena offset of list k on the evaluation stack; start[sp] = end
+// the selected boundary.  `cap` (intervals a list or the whole stack may hold) is either the full RTD_CSG_CAP or the
+// scene's own bound, which no step of any of its programs can exceed: the capacity checks below then never fire and
+// both stores give the same result.
+template <class Store>
+__device__ inline float csgEval(const DevScene& S, const rt_csg& c, f3 e, f3 d, bool exitHit, uint32_t& tagOut, Store& st) {
+	const int cap = st.cap();
 	int sp = 0;
-	start[0] = 0;
+	CsgStarts start;
 	for (int k = 0; k < c.node_count; k++) {
-		const rt_csg_node& nd = S.csg_nodes[c.node_first + k];
+		const rt_csg_node nd = st.node(S, c, k);
 		if (nd.kind >= RT_CSG_SPHERE) {   // leaf, csg.cpp:99-111
-			int at = start[sp];
-			float tn = csgLeafHit(S, nd, e, d, false, nullptr);
-			float tf = csgLeafHit(S, nd, e, d, true, nullptr);
+			int at = start.get(sp);
+			float tn, tf;
+			csgLeafHits(S, nd, e, d, tn, tf);
 			int n = 0;
-			if (tf > 0 && at < RTD_CSG_CAP && sp < RT_MAX_CSG_LEAVES) {
-				arena[at].a.t = tn; arena[at].a.tag = (uint32_t)k;
-				arena[at].b.t = tf; arena[at].b.tag = (uint32_t)k | 0x100u;
+			if (tf > 0 && at < cap && sp < RT_MAX_CSG_LEAVES) {
+				CsgIv v;
+				v.a.t = tn; v.a.tag = (uint32_t)k;
+				v.b.t = tf; v.b.tag = (uint32_t)k | 0x100u;
+				st.arena(at) = v;
 				n = 1;
 			}
-			if (sp < RT_MAX_CSG_LEAVES) { sp++; start[sp] = at + n; }
+			if (sp < RT_MAX_CSG_LEAVES) { sp++; start.set(sp, at + n); }
 			continue;
 		}
 		if (sp < 2) continue;   // malformed program (rejected at upload); keeps the indices in range regardless
-		const int a0 = start[sp - 2], a1 = start[sp - 1], b1 = start[sp];
-		const CsgIv* l1 = arena + a0; const int n1 = a1 - a0;
-		const CsgIv* l2 = arena + a1; const int n2 = b1 - a1;
+		const int a0 = start.get(sp - 2), a1 = start.get(sp - 1), b1 = start.get(sp);
+		const int n1 = a1 - a0, n2 = b1 - a1;
+		auto l1 = [&](int i) -> CsgIv& { return st.arena(a0 + i); };
+		auto l2 = [&](int i) -> CsgIv& { return st.arena(a1 + i); };
 		int n = 0;
 		if (nd.kind == RT_CSG_UNION) {   // csg.cpp:123-188
-			if (n1 == 0) { for (int i = 0; i < n2; i++) tmp[n++] = l2[i]; }
-			else if (n2 == 0) { for (int i = 0; i < n1; i++) tmp[n++] = l1[i]; }
+			if (n1 == 0) { for (int i = 0; i < n2; i++) st.tmp(n++) = l2(i); }
+			else if (n2 == 0) { for (int i = 0; i < n1; i++) st.tmp(n++) = l1(i); }
 			else {
 				int c1 = 0, c2 = 0;
 				CsgIv cur;
-				if (l1[0].a.t < l2[0].a.t) cur = l1[c1++]; else cur = l2[c2++];
+				if (l1(0).a.t < l2(0).a.t) cur = l1(c1++); else cur = l2(c2++);
 				while (c1 < n1 || c2 < n2) {
 					CsgIv add;
-					if (c1 < n1 && c2 < n2) { if (l1[c1].a.t < l2[c2].a.t) add = l1[c1++]; else add = l2[c2++]; }
-					else if (c1 < n1) add = l1[c1++];
-					else add = l2[c2++];
+					if (c1 < n1 && c2 < n2) { if (l1(c1).a.t < l2(c2).a.t) add = l1(c1++); else add = l2(c2++); }
+					else if (c1 < n1) add = l1(c1++);
+					else add = l2(c2++);
 					if (add.a.t < cur.b.t) cur.b = csgMaxB(cur.b, add.b);
-					else { if (n < RTD_CSG_CAP) tmp[n++] = cur; cur = add; }
+					else { if (n < cap) st.tmp(n++) = cur; cur = add; }
 				}
-				if (n < RTD_CSG_CAP) tmp[n++] = cur;
+				if (n < cap) st.tmp(n++) = cur;
 			}
 		} else if (nd.kind == RT_CSG_INTERSECTION) {   // csg.cpp:190-200
-			for (int c1 = 0; c1 < n1; c1++)
-				for (int c2 = 0; c2 < n2; c2++)
-					if (l1[c1].a.t < l2[c2].b.t && l1[c1].b.t > l2[c2].a.t && n < RTD_CSG_CAP) {
-						tmp[n].a = csgMaxB(l1[c1].a, l2[c2].a);
-						tmp[n].b = csgMinB(l1[c1].b, l2[c2].b);
-						n++;
+			for (int c1 = 0; c1 < n1; c1++) {
+				const CsgIv x = l1(c1);
+				for (int c2 = 0; c2 < n2; c2++) {
+					const CsgIv y = l2(c2);
+					if (x.a.t < y.b.t && x.b.t > y.a.t && n < cap) {
+						CsgIv v;
+						v.a = csgMaxB(x.a, y.a);
+						v.b = csgMinB(x.b, y.b);
+						st.tmp(n++) = v;
 					}
+				}
+			}
 			// std::sort by entry t; for <= 16 elements libstdc++ runs a plain (stable) insertion sort
 			for (int i = 1; i < n; i++) {
-				CsgIv v = tmp[i];
+				const CsgIv v = st.tmp(i);
 				int j = i;
-				while (j > 0 && v.a.t < tmp[j - 1].a.t) { tmp[j] = tmp[j - 1]; j--; }
-				tmp[j] = v;
+				while (j > 0 && v.a.t < st.tmp(j - 1).a.t) { st.tmp(j) = st.tmp(j - 1); j--; }
+				st.tmp(j) = v;
 			}
 		} else {   // Difference, csg.cpp:202-230
 			for (int c1 = 0; c1 < n1; c1++) {
-				CsgB cur = l1[c1].a;
-				for (int c2 = 0; c2 < n2 && cur.t < l1[c1].b.t; c2++) {
-					CsgIv sub = l2[c2];
+				const CsgIv x = l1(c1);
+				CsgB cur = x.a;
+				for (int c2 = 0; c2 < n2 && cur.t < x.b.t; c2++) {
+					CsgIv sub = l2(c2);
 					sub.a.tag ^= 0x200u; sub.b.tag ^= 0x200u;
-					if (l1[c1].a.t < sub.b.t && l1[c1].b.t > sub.a.t) {
+					if (x.a.t < sub.b.t && x.b.t > sub.a.t) {
 						if (sub.a.t < cur.t) cur = sub.b;
 						else {
-							if (n < RTD_CSG_CAP) { tmp[n].a = cur; tmp[n].b = sub.a; n++; }
+							if (n < cap) { CsgIv v; v.a = cur; v.b = sub.a; st.tmp(n++) = v; }
 							cur = sub.b;
 						}
 					}
 				}
-				if (cur.t < l1[c1].b.t && n < RTD_CSG_CAP) { tmp[n].a = cur; tmp[n].b = l1[c1].b; n++; }
+				if (cur.t < x.b.t && n < cap) { CsgIv v; v.a = cur; v.b = x.b; st.tmp(n++) = v; }
 			}
 		}
-		if (a0 + n > RTD_CSG_CAP) n = RTD_CSG_CAP - a0;
-		for (int i = 0; i < n; i++) arena[a0 + i] = tmp[i];
+		if (a0 + n > cap) n = cap - a0;
+		for (int i = 0; i < n; i++) st.arena(a0 + i) = st.tmp(i);
 		sp--;
-		start[sp] = a0 + n;
+		start.set(sp, a0 + n);
 	}
 	float t = 0;
 	tagOut = 0;
 	if (sp >= 1) {
-		const int a0 = start[sp - 1], a1 = start[sp];
+		const int a0 = start.get(sp - 1), a1 = start.get(sp);
 		for (int i = a0; i < a1 && t == 0; i++) {   // csg.cpp:13-22
-			if (!exitHit && arena[i].a.t > 0) { t = arena[i].a.t; tagOut = arena[i].a.tag; }
-			else if (exitHit && arena[i].b.t > 0) { t = arena[i].b.t; tagOut = arena[i].b.tag; }
+			const CsgIv v = st.arena(i);
+			if (!exitHit && v.a.t > 0) { t = v.a.t; tagOut = v.a.tag; }
+			else if (exitHit && v.b.t > 0) { t = v.b.t; tagOut = v.b.tag; }
 		}
 	}
 	return t;
 }
+__device__ inline float csgEval(const DevScene& S, const rt_csg& c, f3 e, f3 d, bool exitHit, uint32_t& tagOut) {
+	CsgScratch st;
+	return csgEval(S, c, e, d, exitHit, tagOut, st);
+}
 
 // The normal csgObject::getNormal would return (cachedHitNormal) for the boundary `tag` of the ray (e, d).
-__device__ inline f3 csgNormal(const DevScene& S, const rt_csg& c, f3 e, f3 d, uint32_t tag) {
-	const rt_csg_node& nd = S.csg_nodes[c.node_first + (int)(tag & 0xffu)];
+template <class Store>
+__device__ inline f3 csgNormal(const DevScene& S, const rt_csg& c, f3 e, f3 d, uint32_t tag, const Store& st) {
+	const rt_csg_node nd = st.node(S, c, (int)(tag & 0xffu));
 	f3 n;
 	csgLeafHit(S, nd, e, d, (tag & 0x100u) != 0, &n);
 	return (tag & 0x200u) ? -n : n;
+}
+__device__ inline f3 csgNormal(const DevScene& S, const rt_csg& c, f3 e, f3 d, uint32_t tag) {
+	CsgScratch st;
+	return csgNormal(S, c, e, d, tag, st);
 }
 
 // EasyBMP BMP::operator()(i,j): both indices clamped (EasyBMP.cpp:310-329)

@@ -56,18 +56,21 @@ struct RtQueue { float* f; uint32_t cap; };
 enum { RQ_OX, RQ_OY, RQ_OZ, RQ_DX, RQ_DY, RQ_DZ, RQ_WR, RQ_WG, RQ_WB, RQ_PIX, RQ_PATH, RQ_COMPS };   // ray: origin, direction (unnormalised), RGB weight, pixel key, tree position
 enum { HQ_PRIM, HQ_T, HQ_TAG, HQ_COMPS };                                                             // hit: primitive reference, t, csg boundary tag
 enum { SQ_PX, SQ_PY, SQ_PZ, SQ_NX, SQ_NY, SQ_NZ, SQ_VX, SQ_VY, SQ_VZ, SQ_KDR, SQ_KDG, SQ_KDB, SQ_KSR, SQ_KSG, SQ_KSB,
-       SQ_SHIN, SQ_WR, SQ_WG, SQ_WB, SQ_PIX, SQ_PATH, SQ_COMPS };                                     // surface: what the light loop needs (p, N, V, kd, ks, shininess, weight)
+       SQ_SHIN, SQ_WR, SQ_WG, SQ_WB, SQ_PIX, SQ_PATH, SQ_COMPS };
+enum { TQ_PRIM, TQ_PX, TQ_PY, TQ_PZ, TQ_DX, TQ_DY, TQ_DZ, TQ_NX, TQ_NY, TQ_NZ, TQ_REFR, TQ_WR, TQ_WG, TQ_WB, TQ_PIX, TQ_PATH, TQ_COMPS };   // transmission request: hit primitive, point, incoming direction, normal, index of refraction, weight of the transmitted ray                                     // surface: what the light loop needs (p, N, V, kd, ks, shininess, weight)
 
 #ifndef RT_PROF
 #define RT_PROF 0
 #endif
 #define RT_TRACE_LEN 2048
-#define RT_COUNTER_RESET_BYTES (4 * 4)
+#define RT_COUNTER_RESET_BYTES (6 * 4)
 struct RtCounters {
 	uint32_t next_count;      // rays appended to the next level's queue
 	uint32_t surf_count;      // surface records appended
 	uint32_t head_nearest;    // work cursors of the persistent kernels
-	uint32_t head_shadow;     // ---- everything above is reset at the start of every level (RT_COUNTER_RESET_BYTES) ----
+	uint32_t head_shadow;
+	uint32_t trans_count;     // transmission requests appended by k_shade, consumed by k_transmit
+	uint32_t reserved;        // ---- everything above is reset at the start of every level (RT_COUNTER_RESET_BYTES) ----
 	uint32_t overflow;        // an append found its queue full (the batch is re-run in halves)
 	uint32_t pad;
 	unsigned long long nodes_nearest, prims_nearest;   // RT_FLAG_COUNTERS: 64 B nodes read / primitive tests in k_intersect
@@ -88,7 +91,8 @@ void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, i
 void rtk_load_rays(hipStream_t st, const float* a, const float* b, uint32_t n, int bIsTarget, RtQueue rq, uint32_t pixBase);
 void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr);
 void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, uint8_t* hit, int32_t* id, float* t);
-void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtCounters* ctr, RtAccum A,
+void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint32_t maxRequests, RtQueue nq, RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth);
+void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
                uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT);
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                       RtAccum A, uint32_t aaSq, RtCounters* ctr);

@@ -845,8 +845,8 @@ __global__ __launch_bounds__(kBlock) void k_export_hits(DevScene S, RtQueue hq, 
 // Where the exit search on the ray's own object fails, the reference continues from whatever an earlier ray left in
 // the object's hit cache; like the oracle restatement this uses the current point / previous normal instead.
 // ---------------------------------------------------------------------------------------------------------
-template <bool CSG>
-__device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refraction, f3 inPoint, f3 inVector, f3 inNormal, f3& outPoint, f3& outVector) {
+template <bool CSG, class Store>
+__device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refraction, f3 inPoint, f3 inVector, f3 inNormal, f3& outPoint, f3& outVector, Store& csgStore) {
 	const uint32_t type = RT_PRIM_TYPE(ref), ix = RT_PRIM_INDEX(ref);
 	if (type == RT_PRIM_PLANE || refraction == 0) {
 		outVector = inVector;
@@ -855,6 +855,8 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 	}
 	f3 currentPoint = inPoint, innerVector = mk3(0, 0, 0), outNormal = mk3(0, 0, 0);
 	refractRay(inVector, inNormal, refraction, innerVector);
+	rt_csg c = {};
+	if (CSG && type == RT_PRIM_CSG) { c = S.csgs[ix]; csgStore.loadProgram(S, c); }
 	bool result = false;
 	int reflections = 0;
 	while (!result && reflections < RT_MAX_REFLECTIONS) {
@@ -877,11 +879,10 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 			if (!(t < 0)) hp = currentPoint + t * innerVector;
 			boxNormal(b.b, hp, outNormal);
 		} else if (CSG) {
-			const rt_csg c = S.csgs[ix];
 			uint32_t tag = 0;
-			const float t = csgEval(S, c, currentPoint, innerVector, true, tag);
+			const float t = csgEval(S, c, currentPoint, innerVector, true, tag, csgStore);
 			hp = currentPoint + t * innerVector;   // csgObject::rayhit always rewrites cachedHitpoint (csg.cpp:24)
-			if (t != 0.0f) outNormal = csgNormal(S, c, currentPoint, innerVector, tag);
+			if (t != 0.0f) outNormal = csgNormal(S, c, currentPoint, innerVector, tag, csgStore);
 		}
 		outPoint = hp;
 		result = refractRay(innerVector, outNormal, refraction, outVector);
@@ -898,7 +899,7 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 // shade: everything Object::lightPoint does except the shadow rays
 // ---------------------------------------------------------------------------------------------------------
 template <bool CSG>
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtCounters* ctr,
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
                                                   RtAccum A, uint32_t aaSq, int maxDepth, int wantSurfaces,
                                                   uint8_t* outHit, int32_t* outId, float* outT) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -921,9 +922,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 	}
 	if (live && !hit) accumAdd(A, pixel, w * background);   // q1.cpp:143-145 / objects.cpp:68-69,94-95
 
-	bool wantR = false, wantT = false, wantS = false;
+	bool wantR = false, wantX = false, wantS = false;
+	float refraction = 0;
 	f3 p = mk3(0, 0, 0), N = mk3(0, 0, 0), V = mk3(0, 0, 0);
-	f3 rO = p, rD = p, rW = p, tO = p, tD = p, tW = p, wl = p;
+	f3 rO = p, rD = p, rW = p, tW = p, wl = p;
 	float kd[3] = { 0, 0, 0 }, ks[3] = { 0, 0, 0 }, shininess = 0;
 	if (hit) {
 		const uint32_t type = RT_PRIM_TYPE(prim), ix = RT_PRIM_INDEX(prim);
@@ -976,16 +978,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 			if (depth + 1 > maxDepth) accumAdd(A, pixel, rW * background);   // raytracer.cpp:308-313 -> objects.cpp:68-69
 			else wantR = true;
 		}
-		if (transmissive) {   // objects.cpp:81-104
-			f3 outPoint, outVector;
-			if (transmitRay<CSG>(S, prim, m.refraction, p, d, N, outPoint, outVector)) {
-				tO = outPoint;
-				tD = (outPoint + outVector) - outPoint;
-				tW = w * kt;
-				if (depth + 1 > maxDepth) accumAdd(A, pixel, tW * background);
-				else wantT = true;
-			}
-		}
+		// objects.cpp:81-104: the search for the exit point (Object::transmitRay: up to 16 internal reflections, each a full
+		// hit test of the object) is not done here: a few such rays would hold their whole wave.  They are queued, and
+		// k_transmit works through them with every lane busy.
+		if (transmissive) { wantX = true; tW = w * kt; refraction = m.refraction; }
 		wantS = wantSurfaces != 0;
 	}
 
@@ -995,25 +991,26 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 	uint32_t sr, st, ss;
 	{
 		__shared__ uint32_t waveCount[kBlock / 64][3];
-		__shared__ uint32_t blockBase[2];
-		const unsigned long long mR = __ballot(wantR), mT = __ballot(wantT), mS = __ballot(wantS);
+		__shared__ uint32_t blockBase[3];
+		const unsigned long long mR = __ballot(wantR), mT = __ballot(wantX), mS = __ballot(wantS);
 		const uint32_t lane = __lane_id(), wv = threadIdx.x >> 6;
 		if (lane == 0) { waveCount[wv][0] = (uint32_t)__popcll(mR); waveCount[wv][1] = (uint32_t)__popcll(mT); waveCount[wv][2] = (uint32_t)__popcll(mS); }
 		__syncthreads();
 		uint32_t beforeN = 0, beforeS = 0, totalN = 0, totalS = 0;   // rays / surfaces of the waves before this one, and of the workgroup
+		uint32_t beforeX = 0, totalX = 0;
 		for (uint32_t k = 0; k < kBlock / 64; k++) {
-			const uint32_t cn = waveCount[k][0] + waveCount[k][1], cs = waveCount[k][2];
-			if (k < wv) { beforeN += cn; beforeS += cs; }
-			totalN += cn; totalS += cs;
+			const uint32_t cn = waveCount[k][0], cx = waveCount[k][1], cs = waveCount[k][2];
+			if (k < wv) { beforeN += cn; beforeX += cx; beforeS += cs; }
+			totalN += cn; totalX += cx; totalS += cs;
 		}
 		if (threadIdx.x == 0 && totalN > 0) blockBase[0] = atomicAdd(&ctr->next_count, totalN);
 		if (threadIdx.x == 64 && totalS > 0) blockBase[1] = atomicAdd(&ctr->surf_count, totalS);
+		if (threadIdx.x == 128 && totalX > 0) blockBase[2] = atomicAdd(&ctr->trans_count, totalX);
 		__syncthreads();
 		const unsigned long long below = (1ull << lane) - 1ull;
-		const uint32_t baseN = blockBase[0] + beforeN, baseS = blockBase[1] + beforeS;
-		sr = baseN + (uint32_t)__popcll(mR & below);
-		st = baseN + (uint32_t)__popcll(mR) + (uint32_t)__popcll(mT & below);
-		ss = baseS + (uint32_t)__popcll(mS & below);
+		sr = blockBase[0] + beforeN + (uint32_t)__popcll(mR & below);
+		st = blockBase[2] + beforeX + (uint32_t)__popcll(mT & below);
+		ss = blockBase[1] + beforeS + (uint32_t)__popcll(mS & below);
 	}
 	if (wantR) {
 		if (sr < nq.cap) {
@@ -1023,12 +1020,15 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 			qsu(nq, RQ_PIX, sr, pixKey); qsu(nq, RQ_PATH, sr, path * 2u);
 		} else ctr->overflow = 1;
 	}
-	if (wantT) {
-		if (st < nq.cap) {
-			qsf(nq, RQ_OX, st, tO.x); qsf(nq, RQ_OY, st, tO.y); qsf(nq, RQ_OZ, st, tO.z);
-			qsf(nq, RQ_DX, st, tD.x); qsf(nq, RQ_DY, st, tD.y); qsf(nq, RQ_DZ, st, tD.z);
-			qsf(nq, RQ_WR, st, tW.x); qsf(nq, RQ_WG, st, tW.y); qsf(nq, RQ_WB, st, tW.z);
-			qsu(nq, RQ_PIX, st, pixKey); qsu(nq, RQ_PATH, st, path * 2u + 1u);
+	if (wantX) {
+		if (st < tq.cap) {
+			qsu(tq, TQ_PRIM, st, prim);
+			qsf(tq, TQ_PX, st, p.x); qsf(tq, TQ_PY, st, p.y); qsf(tq, TQ_PZ, st, p.z);
+			qsf(tq, TQ_DX, st, d.x); qsf(tq, TQ_DY, st, d.y); qsf(tq, TQ_DZ, st, d.z);
+			qsf(tq, TQ_NX, st, N.x); qsf(tq, TQ_NY, st, N.y); qsf(tq, TQ_NZ, st, N.z);
+			qsf(tq, TQ_REFR, st, refraction);
+			qsf(tq, TQ_WR, st, tW.x); qsf(tq, TQ_WG, st, tW.y); qsf(tq, TQ_WB, st, tW.z);
+			qsu(tq, TQ_PIX, st, pixKey); qsu(tq, TQ_PATH, st, path);
 		} else ctr->overflow = 1;
 	}
 	if (wantS) {
@@ -1041,6 +1041,56 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 			qsf(sq, SQ_SHIN, ss, shininess);
 			qsf(sq, SQ_WR, ss, wl.x); qsf(sq, SQ_WG, ss, wl.y); qsf(sq, SQ_WB, ss, wl.z);
 			qsu(sq, SQ_PIX, ss, pixKey); qsu(sq, SQ_PATH, ss, path);
+		} else ctr->overflow = 1;
+	}
+}
+
+// Transmitted rays (objects.cpp:81-104): one request per lane.  The launch covers the most requests the level could have
+// made; the count is read from the counters the shading kernel just wrote.  A request is a chain of up to 16 dependent
+// exit searches and the slowest one sets the length of the launch, so what counts here is the latency of one search:
+// workgroups are single waves and, for CSG objects, the interval lists live in LDS (LDSCSG) whenever the scene's
+// largest program fits (CsgLds; rtk_transmit decides).
+constexpr int kTransmitBlock = 64;
+template <bool CSG, bool LDSCSG>
+__global__ __launch_bounds__(kTransmitBlock) void k_transmit(DevScene S, RtQueue tq, RtQueue nq, RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth) {
+	extern __shared__ __align__(16) uint8_t transmitLds[];
+	const uint32_t i = blockIdx.x * kTransmitBlock + threadIdx.x;
+	const uint32_t n = ctr->trans_count < tq.cap ? ctr->trans_count : tq.cap;
+	if (blockIdx.x * kTransmitBlock >= n) return;   // wave-uniform: whole workgroups beyond the requests leave at once
+	bool want = false;
+	f3 tO = mk3(0, 0, 0), tD = tO, tW = tO;
+	uint32_t pixKey = 0, path = 1;
+	if (i < n) {
+		const uint32_t prim = qu(tq, TQ_PRIM, i);
+		const f3 p = mk3(qf(tq, TQ_PX, i), qf(tq, TQ_PY, i), qf(tq, TQ_PZ, i));
+		const f3 d = mk3(qf(tq, TQ_DX, i), qf(tq, TQ_DY, i), qf(tq, TQ_DZ, i));
+		const f3 N = mk3(qf(tq, TQ_NX, i), qf(tq, TQ_NY, i), qf(tq, TQ_NZ, i));
+		tW = mk3(qf(tq, TQ_WR, i), qf(tq, TQ_WG, i), qf(tq, TQ_WB, i));
+		pixKey = qu(tq, TQ_PIX, i); path = qu(tq, TQ_PATH, i);
+		f3 outPoint, outVector;
+		bool ok;
+		if constexpr (CSG && LDSCSG) {
+			CsgLds store = csgLdsStore(transmitLds, kTransmitBlock, (int)threadIdx.x, S.csg_cap);
+			ok = transmitRay<CSG>(S, prim, qf(tq, TQ_REFR, i), p, d, N, outPoint, outVector, store);
+		} else {
+			CsgScratch store;
+			ok = transmitRay<CSG>(S, prim, qf(tq, TQ_REFR, i), p, d, N, outPoint, outVector, store);
+		}
+		if (ok) {
+			tO = outPoint;
+			tD = (outPoint + outVector) - outPoint;
+			const int depth = 31 - __clz((int)path);
+			if (depth + 1 > maxDepth) accumAdd(A, pixKey / aaSq, tW * ld3(S.background));   // raytracer.cpp:308-313 -> objects.cpp:94-95
+			else want = true;
+		}
+	}
+	const uint32_t st = wavePush(want, &ctr->next_count);
+	if (want) {
+		if (st < nq.cap) {
+			qsf(nq, RQ_OX, st, tO.x); qsf(nq, RQ_OY, st, tO.y); qsf(nq, RQ_OZ, st, tO.z);
+			qsf(nq, RQ_DX, st, tD.x); qsf(nq, RQ_DY, st, tD.y); qsf(nq, RQ_DZ, st, tD.z);
+			qsf(nq, RQ_WR, st, tW.x); qsf(nq, RQ_WG, st, tW.y); qsf(nq, RQ_WB, st, tW.z);
+			qsu(nq, RQ_PIX, st, pixKey); qsu(nq, RQ_PATH, st, path * 2u + 1u);
 		} else ctr->overflow = 1;
 	}
 }
@@ -1345,10 +1395,19 @@ void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, bool
 void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, uint8_t* hit, int32_t* id, float* t) {
 	RT_LAUNCH(k_export_hits, n, st, S, hq, n, hit, id, t);
 }
-void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtCounters* ctr, RtAccum A,
+void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
                uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT) {
-	if (csg) RT_LAUNCH((k_shade<true>), n, st, S, rq, hq, n, nq, sq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT);
-	else RT_LAUNCH((k_shade<false>), n, st, S, rq, hq, n, nq, sq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT);
+	if (csg) RT_LAUNCH((k_shade<true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT);
+	else RT_LAUNCH((k_shade<false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT);
+}
+void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint32_t maxRequests, RtQueue nq, RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth) {
+	if (maxRequests == 0) return;
+	const dim3 grid((maxRequests + kTransmitBlock - 1) / kTransmitBlock), block(kTransmitBlock);
+	const size_t lds = RTD_CSG_LDS_BYTES(kTransmitBlock, S.csg_cap, S.csg_nodes_max);
+	static const bool noLds = getenv("RT_NO_CSG_LDS") != nullptr;
+	if (!csg) hipLaunchKernelGGL((k_transmit<false, false>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth);
+	else if (lds <= 64u * 1024u && !noLds) hipLaunchKernelGGL((k_transmit<true, true>), grid, block, lds, st, S, tq, nq, ctr, A, aaSq, maxDepth);
+	else hipLaunchKernelGGL((k_transmit<true, false>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth);
 }
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                       RtAccum A, uint32_t aaSq, RtCounters* ctr) {

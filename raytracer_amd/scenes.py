@@ -179,6 +179,54 @@ def c3_scene(out_dir):
     return path
 
 
+def random_csg_scene(out_dir, seed=0, n_objects=24, max_leaves=16):
+    """Random CSG programs for the parity tests: `n_objects` csgobjects on a lattice, each a random binary tree of
+    union / intersection / difference over 2..max_leaves overlapping spheres and boxes (multi-interval lists, empty
+    operands, deep stacks), a third of them reflective and a third transmissive."""
+    os.makedirs(out_dir, exist_ok=True)
+    rng = np.random.default_rng(seed)
+
+    def leaf(cx, cy, cz, r):
+        ox, oy, oz = (float(v) for v in rng.uniform(-0.6, 0.6, 3) * r)
+        if rng.random() < 0.5:
+            return {"type": "sphere", "position": [_fmt(cx + ox), _fmt(cy + oy), _fmt(cz + oz)], "radius": _fmt(float(rng.uniform(0.35, 0.8)) * r)}
+        hx, hy, hz = (float(v) for v in rng.uniform(0.25, 0.8, 3) * r)
+        return {"type": "box", "point1": [_fmt(cx + ox - hx), _fmt(cy + oy - hy), _fmt(cz + oz - hz)],
+                "point2": [_fmt(cx + ox + hx), _fmt(cy + oy + hy), _fmt(cz + oz + hz)]}
+
+    def tree(leaves, cx, cy, cz, r):
+        if leaves == 1:
+            return leaf(cx, cy, cz, r)
+        left = int(rng.integers(1, leaves))
+        return {"operation": str(rng.choice(["union", "union", "intersection", "difference"])),
+                "first": tree(left, cx, cy, cz, r), "second": tree(leaves - left, cx, cy, cz, r)}
+
+    objects = [{"type": "plane", "position": [0, -1.2, 0], "normal": [0, 1, 0],
+                "material": {"ambient": [0.1, 0.1, 0.1], "diffuse": [0.5, 0.5, 0.45], "reflective": [0.15, 0.15, 0.15]}}]
+    cols = int(math.ceil(math.sqrt(n_objects)))
+    for k in range(n_objects):
+        i, j = k % cols, k // cols
+        cx, cy, cz = -1.6 * (cols - 1) / 2 + 1.6 * i, float(rng.uniform(-0.5, 0.6)), -4.0 - 1.6 * j
+        mat = {"ambient": [0.1, 0.1, 0.12], "diffuse": [_fmt(float(v)) for v in rng.uniform(0.2, 0.8, 3)],
+               "specular": [0.4, 0.4, 0.4], "shininess": 20.0}
+        if k % 3 == 0:
+            mat["reflective"] = [0.4, 0.4, 0.4]
+        if k % 3 == 1:
+            mat["transmissive"] = [0.5, 0.5, 0.5]
+            mat["refraction"] = [1.0, 1.33, 1.5, 0.0][(k // 3) % 4]
+        obj = {"type": "csgobject", "material": mat}
+        obj.update(tree(int(rng.integers(2, max_leaves + 1)), cx, cy, cz, 0.7))
+        objects.append(obj)
+    scene = {"camera": {"field": 60, "background": [0.1, 0.12, 0.2]}, "objects": objects,
+             "lights": [{"type": "ambient", "color": [0.3, 0.3, 0.3]},
+                        {"type": "point", "color": [0.7, 0.7, 0.7], "position": [1.0, 4.0, 0.0]},
+                        {"type": "directional", "color": [0.4, 0.4, 0.4], "direction": [-0.3, -1.0, -0.5]}]}
+    path = os.path.join(out_dir, f"csg_random_{seed}.json")
+    with open(path, "w") as f:
+        json.dump(scene, f)
+    return path
+
+
 def c4_scene(out_dir, samples=64):
     """BASELINE config 4: a room with CSG furniture lit by a rectangular and a circular area light, `samples` each."""
     os.makedirs(out_dir, exist_ok=True)

@@ -120,6 +120,27 @@ def test_c3_nested_csg_depth5(tmp_path):
     sc.close()
 
 
+@pytest.mark.parametrize("seed,max_leaves", [(1, 5), (2, 16), (3, 16)])
+def test_random_csg_programs(tmp_path, seed, max_leaves):
+    """Random operator trees up to the 16-leaf limit (multi-interval lists, empty operands): the interval evaluation in all
+    its homes -- packets, per-lane walks, shadow rays, the exit search of transmitted rays -- against the oracle."""
+    flat = rt.FlatScene.from_json(scenes.random_csg_scene(str(tmp_path), seed=seed, max_leaves=max_leaves))
+    sc = rt.Scene(flat, 0)
+    W, H = 320, 180
+    cam = rt.Camera(flat.fov, W, H, eye=(0, 1.0, 1.5), rot_x=-0.2)
+    s = primary_targets_np(cam, W, H)
+    e = np.tile(np.array(cam.c.eye[:], np.float32), (W * H, 1))
+    r = sc.trace_batch(e, s, max_depth=4)
+    o = oracle.trace_batch(flat, e, s, max_depth=4, seed=1, threads=8)
+    assert np.array_equal(r["id"], o["id"]) and np.array_equal(bits(r["t"]), bits(o["t"]))
+    assert sc.last_stats["rays_nearest"] == o["rays_nearest"] and sc.last_stats["rays_shadow"] == o["rays_shadow"]
+    d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(o["rgb"]).astype(int)).max(axis=1)
+    assert (d8 > 1).mean() < 1e-3, f"{(d8 > 1).sum()} pixels differ by more than 1/255"
+    img = sc.render(W, H, camera=cam, max_depth=4)          # the frame path (packets) agrees with the batch path
+    assert np.array_equal(bits(img.reshape(-1, 3)), bits(r["rgb"]))
+    sc.close()
+
+
 def test_c4_area_lights_64_samples(tmp_path):
     flat = rt.FlatScene.from_json(scenes.c4_scene(str(tmp_path), samples=64))
     sc = rt.Scene(flat, 0)

@@ -373,63 +373,118 @@ __device__ inline float csgEval(const DevScene& S, const rt_csg& c, f3 e, f3 d, 
 		auto l1 = [&](int i) -> CsgIv& { return st.arena(a0 + i); };
 		auto l2 = [&](int i) -> CsgIv& { return st.arena(a1 + i); };
 		int n = 0;
-		if (nd.kind == RT_CSG_UNION) {   // csg.cpp:123-188
-			if (n1 == 0) { for (int i = 0; i < n2; i++) st.tmp(n++) = l2(i); }
-			else if (n2 == 0) { for (int i = 0; i < n1; i++) st.tmp(n++) = l1(i); }
-			else {
-				int c1 = 0, c2 = 0;
-				CsgIv cur;
-				if (l1(0).a.t < l2(0).a.t) cur = l1(c1++); else cur = l2(c2++);
-				while (c1 < n1 || c2 < n2) {
+		// The result replaces both operands at a0.  With an empty operand it is already there or empty; with a one-interval
+		// first list (every step of a program whose right operands are the composite ones) that interval is held in a
+		// register and the result written straight over the operands: output k lands on a slot of the second list that the
+		// merge has passed (at most k + 1 - c1 of its elements are flushed when c2 are consumed) or on x's own.  Only longer
+		// first lists go through `tmp`.  Same comparisons in the same order as the general form below, hence the same list.
+		if (n1 == 0) n = nd.kind == RT_CSG_UNION ? n2 : 0;
+		else if (n2 == 0 && nd.kind != RT_CSG_DIFFERENCE) n = nd.kind == RT_CSG_UNION ? n1 : 0;
+		else if (n1 == 1) {
+			const CsgIv x = l1(0);
+			auto out = [&](int k) -> CsgIv& { return st.arena(a0 + k); };
+			if (nd.kind == RT_CSG_UNION) {
+				int c2 = 0;
+				bool xLeft = true;
+				CsgIv y = l2(0), cur;
+				if (x.a.t < y.a.t) { cur = x; xLeft = false; } else { cur = y; c2 = 1; }
+				while (xLeft || c2 < n2) {
 					CsgIv add;
-					if (c1 < n1 && c2 < n2) { if (l1(c1).a.t < l2(c2).a.t) add = l1(c1++); else add = l2(c2++); }
-					else if (c1 < n1) add = l1(c1++);
-					else add = l2(c2++);
+					if (c2 < n2) y = l2(c2);
+					if (xLeft && c2 < n2) { if (x.a.t < y.a.t) { add = x; xLeft = false; } else { add = y; c2++; } }
+					else if (xLeft) { add = x; xLeft = false; }
+					else { add = y; c2++; }
 					if (add.a.t < cur.b.t) cur.b = csgMaxB(cur.b, add.b);
-					else { if (n < cap) st.tmp(n++) = cur; cur = add; }
+					else { out(n++) = cur; cur = add; }
 				}
-				if (n < cap) st.tmp(n++) = cur;
-			}
-		} else if (nd.kind == RT_CSG_INTERSECTION) {   // csg.cpp:190-200
-			for (int c1 = 0; c1 < n1; c1++) {
-				const CsgIv x = l1(c1);
+				out(n++) = cur;
+			} else if (nd.kind == RT_CSG_INTERSECTION) {
 				for (int c2 = 0; c2 < n2; c2++) {
 					const CsgIv y = l2(c2);
-					if (x.a.t < y.b.t && x.b.t > y.a.t && n < cap) {
+					if (x.a.t < y.b.t && x.b.t > y.a.t) {
 						CsgIv v;
 						v.a = csgMaxB(x.a, y.a);
 						v.b = csgMinB(x.b, y.b);
-						st.tmp(n++) = v;
+						out(n++) = v;
 					}
 				}
-			}
-			// std::sort by entry t; for <= 16 elements libstdc++ runs a plain (stable) insertion sort
-			for (int i = 1; i < n; i++) {
-				const CsgIv v = st.tmp(i);
-				int j = i;
-				while (j > 0 && v.a.t < st.tmp(j - 1).a.t) { st.tmp(j) = st.tmp(j - 1); j--; }
-				st.tmp(j) = v;
-			}
-		} else {   // Difference, csg.cpp:202-230
-			for (int c1 = 0; c1 < n1; c1++) {
-				const CsgIv x = l1(c1);
+				for (int i = 1; i < n; i++) {
+					const CsgIv v = out(i);
+					int j = i;
+					while (j > 0 && v.a.t < out(j - 1).a.t) { out(j) = out(j - 1); j--; }
+					if (j != i) out(j) = v;
+				}
+			} else {
 				CsgB cur = x.a;
 				for (int c2 = 0; c2 < n2 && cur.t < x.b.t; c2++) {
 					CsgIv sub = l2(c2);
 					sub.a.tag ^= 0x200u; sub.b.tag ^= 0x200u;
 					if (x.a.t < sub.b.t && x.b.t > sub.a.t) {
-						if (sub.a.t < cur.t) cur = sub.b;
-						else {
-							if (n < cap) { CsgIv v; v.a = cur; v.b = sub.a; st.tmp(n++) = v; }
-							cur = sub.b;
+						if (!(sub.a.t < cur.t)) { CsgIv v; v.a = cur; v.b = sub.a; out(n++) = v; }
+						cur = sub.b;
+					}
+				}
+				if (cur.t < x.b.t) { CsgIv v; v.a = cur; v.b = x.b; out(n++) = v; }
+			}
+		} else {
+			if (nd.kind == RT_CSG_UNION) {   // csg.cpp:123-188
+				if (n1 == 0) { for (int i = 0; i < n2; i++) st.tmp(n++) = l2(i); }
+				else if (n2 == 0) { for (int i = 0; i < n1; i++) st.tmp(n++) = l1(i); }
+				else {
+					int c1 = 0, c2 = 0;
+					CsgIv cur;
+					if (l1(0).a.t < l2(0).a.t) cur = l1(c1++); else cur = l2(c2++);
+					while (c1 < n1 || c2 < n2) {
+						CsgIv add;
+						if (c1 < n1 && c2 < n2) { if (l1(c1).a.t < l2(c2).a.t) add = l1(c1++); else add = l2(c2++); }
+						else if (c1 < n1) add = l1(c1++);
+						else add = l2(c2++);
+						if (add.a.t < cur.b.t) cur.b = csgMaxB(cur.b, add.b);
+						else { if (n < cap) st.tmp(n++) = cur; cur = add; }
+					}
+					if (n < cap) st.tmp(n++) = cur;
+				}
+			} else if (nd.kind == RT_CSG_INTERSECTION) {   // csg.cpp:190-200
+				for (int c1 = 0; c1 < n1; c1++) {
+					const CsgIv x = l1(c1);
+					for (int c2 = 0; c2 < n2; c2++) {
+						const CsgIv y = l2(c2);
+						if (x.a.t < y.b.t && x.b.t > y.a.t && n < cap) {
+							CsgIv v;
+							v.a = csgMaxB(x.a, y.a);
+							v.b = csgMinB(x.b, y.b);
+							st.tmp(n++) = v;
 						}
 					}
 				}
-				if (cur.t < x.b.t && n < cap) { CsgIv v; v.a = cur; v.b = x.b; st.tmp(n++) = v; }
+				// std::sort by entry t; for <= 16 elements libstdc++ runs a plain (stable) insertion sort
+				for (int i = 1; i < n; i++) {
+					const CsgIv v = st.tmp(i);
+					int j = i;
+					while (j > 0 && v.a.t < st.tmp(j - 1).a.t) { st.tmp(j) = st.tmp(j - 1); j--; }
+					st.tmp(j) = v;
+				}
+			} else {   // Difference, csg.cpp:202-230
+				for (int c1 = 0; c1 < n1; c1++) {
+					const CsgIv x = l1(c1);
+					CsgB cur = x.a;
+					for (int c2 = 0; c2 < n2 && cur.t < x.b.t; c2++) {
+						CsgIv sub = l2(c2);
+						sub.a.tag ^= 0x200u; sub.b.tag ^= 0x200u;
+						if (x.a.t < sub.b.t && x.b.t > sub.a.t) {
+							if (sub.a.t < cur.t) cur = sub.b;
+							else {
+								if (n < cap) { CsgIv v; v.a = cur; v.b = sub.a; st.tmp(n++) = v; }
+								cur = sub.b;
+							}
+						}
+					}
+					if (cur.t < x.b.t && n < cap) { CsgIv v; v.a = cur; v.b = x.b; st.tmp(n++) = v; }
+				}
 			}
+			if (a0 + n > cap) n = cap - a0;
+			for (int i = 0; i < n; i++) st.arena(a0 + i) = st.tmp(i);
 		}
-		if (a0 + n > cap) n = cap - a0;
-		for (int i = 0; i < n; i++) st.arena(a0 + i) = st.tmp(i);
 		sp--;
 		start.set(sp, a0 + n);
 	}

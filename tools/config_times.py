@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Frame times of the BASELINE.json configurations other than the bench one (C3, C4, C5 at a reduced triangle count)."""
-import os, sys, time, tempfile
+import gzip, os, shutil, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import raytracer_amd as rt
@@ -8,7 +8,7 @@ from raytracer_amd import scenes
 
 def run(name, path, W, H, aa=(1, 1), max_depth=16, eye=(0, 0, 0), rot_x=0.0, reps=5):
     t0 = time.perf_counter()
-    flat = rt.FlatScene.from_json(path)
+    flat = rt.FlatScene.load(path) if path.endswith(".rtscene") else rt.FlatScene.from_json(path)
     t_load = time.perf_counter() - t0
     sc = rt.Scene(flat, 0)
     cam = rt.Camera(flat.fov, W, H, eye=eye, rot_x=rot_x)
@@ -24,6 +24,14 @@ def run(name, path, W, H, aa=(1, 1), max_depth=16, eye=(0, 0, 0), rot_x=0.0, rep
 
 only = os.environ.get("CONFIG", "")
 with tempfile.TemporaryDirectory() as tmp:
+  if only in ("", "C1"):   # the reference's bundled scenes (tests/golden/scenes: the loader's flat form of scenes/a..m.json) at its own 640x480
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scenes")
+    for f in sorted(os.listdir(gold)):
+      if f.endswith(".rtscene.gz") and f[0] in os.environ.get("C1_SCENES", "abcdefghijklm"):
+        dst = os.path.join(tmp, f[:-3])
+        with gzip.open(os.path.join(gold, f), "rb") as a, open(dst, "wb") as b:
+          shutil.copyfileobj(a, b)
+        run(f"C1 scene {f[0]} 640x480", dst, 640, 480, reps=10)
   if only in ("", "C3"):
     run("C3 csg 1080p depth5", scenes.c3_scene(tmp), 1920, 1080, max_depth=5, eye=(0, 1.0, 2.0), rot_x=-0.25)
   if only in ("", "C4"):

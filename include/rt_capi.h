@@ -144,7 +144,9 @@ int rt_shadow_batch(rt_scene* scene, const float* point, const float* light_pos,
  * dense frame `src_dev` into `dst_dev` (both width*height*3 floats on the scene's device).  New: the
  * reference is single-process; this is the de-interleave after the RCCL gather. */
 int rt_tiles_merge(rt_scene* scene, const float* src_dev, float* dst_dev, int width, int height, int tile_rank, int tile_ranks, void* stream);
-/* Packs / unpacks the owned tiles of a frame into a dense buffer of rt_tiles_count()*256*3 floats (gather payload). */
+/* Packs / unpacks the owned tiles of a frame into a dense buffer of rt_tiles_count()*256*3 floats (gather payload).
+ * rt_tiles_merge / _pack / _unpack enqueue one kernel on `stream` and return without waiting for it (stream order is the
+ * only synchronisation: the collective that follows is queued behind it, and the host stays free to submit frames). */
 int64_t rt_tiles_count(int width, int height, int tile_rank, int tile_ranks);
 int rt_tiles_pack(rt_scene* scene, const float* frame_dev, float* packed_dev, int width, int height, int tile_rank, int tile_ranks, void* stream);
 int rt_tiles_unpack(rt_scene* scene, const float* packed_dev, float* frame_dev, int width, int height, int tile_rank, int tile_ranks, void* stream);

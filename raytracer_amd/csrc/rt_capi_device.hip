@@ -29,8 +29,9 @@ namespace {
 uint32_t envU32(const char* name, uint32_t dflt) {
 	const char* v = getenv(name);
 	if (!v || !*v) return dflt;
-	unsigned long long x = strtoull(v, nullptr, 10);
-	return x == 0 || x > 0x7fffffffull ? dflt : (uint32_t)x;
+	char* end = nullptr;
+	unsigned long long x = strtoull(v, &end, 10);
+	return end == v || x > 0x7fffffffull ? dflt : (uint32_t)x;   // not a number: the default (0 is a value: RT_PACKET_LEVELS=0)
 }
 
 }  // namespace
@@ -72,7 +73,7 @@ struct rt_scene {
 		uint32_t seed = 0, flags = 0;
 		float* rgb = nullptr;
 		hipStream_t st = nullptr;
-		hipEvent_t evStart = nullptr, evEnd = nullptr, evDone[RT_MAX_LANES]{};
+		hipEvent_t evStart = nullptr, evDone[RT_MAX_LANES]{};
 		int remaining = 0;               // lanes that have not finished their part yet
 		int rc[RT_MAX_LANES]{};
 		std::string err[RT_MAX_LANES];
@@ -641,8 +642,10 @@ void laneWorker(rt_scene* sc, int k) {
 
 // The most intervals a step of any CSG program of the scene can hold (stacked lists together, or the list an operator
 // writes): a leaf gives at most 1, Union n1 + n2, Intersection n1 * n2 (csg.cpp:190-200 pairs every interval with every
-// interval), Difference n1 + n2.  Kernels that keep the lists in LDS size them by this; clamped to the capacity of
-// the general path, whose truncation then applies to both alike.
+// interval), Difference n1 * (n2 + 1) (csg.cpp:202-230: per interval of the first list one piece per overlapping
+// interval of the second and one at the end; n1 + n2 if the lists are disjoint, which this does not rely on).  Kernels
+// that keep the lists in LDS size them by this; clamped to the capacity of the general path, whose truncation then
+// applies to both alike.
 int csgCapacity(const rt_flat_scene* s) {
 	long long need = 1;
 	for (int32_t c = 0; c < s->n_csgs; c++) {
@@ -654,7 +657,7 @@ int csgCapacity(const rt_flat_scene* s) {
 			else if (stack.size() >= 2) {
 				const long long n2 = stack.back(); stack.pop_back();
 				const long long n1 = stack.back(); stack.pop_back();
-				const long long n = std::min<long long>(kind == RT_CSG_INTERSECTION ? n1 * n2 : n1 + n2, 1 << 20);
+				const long long n = std::min<long long>(kind == RT_CSG_INTERSECTION ? n1 * n2 : kind == RT_CSG_DIFFERENCE ? n1 * (n2 + 1) : n1 + n2, 1 << 20);
 				need = std::max(need, n);
 				total += n - n1 - n2;
 				stack.push_back(n);
@@ -696,7 +699,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	HIPCHK(hipGetDeviceProperties(&prop, device));
 	rt_scene* sc = new rt_scene();
 	sc->device = device;
-	sc->maxBlocks = std::max(1, prop.multiProcessorCount) * (int)envU32("RT_BLOCKS_PER_CU", 8);
+	sc->maxBlocks = std::max(1, prop.multiProcessorCount) * (int)std::max<uint32_t>(1, envU32("RT_BLOCKS_PER_CU", 8));
 	auto fail = [&](int rc) { rt_scene_free(sc); return rc; };
 	DevScene& D = sc->dev;
 	int rc;
@@ -766,14 +769,14 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	sc->pointLights = const_cast<int32_t*>(plDev);
 
 	sc->qcap = std::max<uint32_t>(1024, envU32("RT_QUEUE_RAYS", 8u << 20));
-	const int nLanes = (int)std::min<uint32_t>(RT_MAX_LANES, envU32("RT_LANES", 4));   // the box exposes 4 hardware queues per process
+	const int nLanes = (int)std::min<uint32_t>(RT_MAX_LANES, std::max<uint32_t>(1, envU32("RT_LANES", 4)));   // the box exposes 4 hardware queues per process
 	sc->lanes.resize(nLanes);
 	// lane 0 runs on the caller's stream (renderShard); creating a stream it would not use would still claim one of
 	// the process's 4 hardware queues and push a working lane onto a shared one
 	for (int i = 0; i < nLanes; i++)
 		if ((rc = sc->initLane(sc->lanes[i], i > 0 || getenv("RT_LANE0_OWN_STREAM") != nullptr))) return fail(rc);
 	for (auto& j : sc->jobs) {
-		bool ok = hipEventCreate(&j.evStart) == hipSuccess && hipEventCreate(&j.evEnd) == hipSuccess;
+		bool ok = hipEventCreate(&j.evStart) == hipSuccess;
 		for (int i = 0; i < nLanes && ok; i++) ok = hipEventCreate(&j.evDone[i]) == hipSuccess;
 		if (!ok) { rt::set_error("hipEventCreate failed"); return fail(RT_EHIP); }
 	}
@@ -802,7 +805,6 @@ void rt_scene_free(rt_scene* sc) {
 	}
 	for (auto& j : sc->jobs) {
 		if (j.evStart) (void)hipEventDestroy(j.evStart);
-		if (j.evEnd) (void)hipEventDestroy(j.evEnd);
 		for (auto& e : j.evDone) if (e) (void)hipEventDestroy(e);
 	}
 	delete sc;
@@ -866,12 +868,18 @@ int rt_render_wait(rt_scene* sc, uint64_t ticket, rt_stats* stats) {
 			retire();
 			return rc;
 		}
+	// The caller's stream is made to wait for the shards (work queued on it afterwards sees the frame); the host waits for
+	// the shards' own events only -- the stream may already hold later frames' work (lane 0 runs on it) and the caller's
+	// collectives, which this frame does not depend on.
 	hipError_t e = hipSuccess;
-	for (int k = 0; k < job->nShards && e == hipSuccess; k++) e = hipStreamWaitEvent(job->st, job->evDone[k], 0);
-	if (e == hipSuccess) e = hipEventRecord(job->evEnd, job->st);
-	if (e == hipSuccess) e = hipStreamSynchronize(job->st);
 	rt_stats total{};
-	if (e == hipSuccess) e = hipEventElapsedTime(&total.gpu_ms, job->evStart, job->evEnd);
+	for (int k = 0; k < job->nShards && e == hipSuccess; k++) e = hipStreamWaitEvent(job->st, job->evDone[k], 0);
+	for (int k = 0; k < job->nShards && e == hipSuccess; k++) {
+		e = hipEventSynchronize(job->evDone[k]);
+		float ms = 0;
+		if (e == hipSuccess) e = hipEventElapsedTime(&ms, job->evStart, job->evDone[k]);
+		total.gpu_ms = std::max(total.gpu_ms, ms);
+	}
 	for (int k = 0; k < job->nShards; k++) {
 		const rt_stats& p = job->part[k];
 		total.rays_nearest += p.rays_nearest; total.rays_shadow += p.rays_shadow; total.batch_splits += p.batch_splits;
@@ -1005,9 +1013,9 @@ static int tilesCopy(rt_scene* sc, const float* src, float* dst, int width, int 
 	if (!sc || !src || !dst || rt_tiles_count(width, height, tile_rank, tile_ranks) < 0) { rt::set_error("rt_tiles_*: bad argument"); return RT_EINVAL; }
 	HIPCHK(hipSetDevice(sc->device));
 	hipStream_t st = static_cast<hipStream_t>(stream);
+	// enqueued, not waited for: between a rendered frame and its gather the host must stay free to submit the next frame
 	rtk_tiles_copy(st, src, dst, width, height, tile_rank, tile_ranks, (uint32_t)(localTiles(width, height, tile_rank, tile_ranks) * 256), mode);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipStreamSynchronize(st));
 	return RT_OK;
 }
 int rt_tiles_pack(rt_scene* sc, const float* frame_dev, float* packed_dev, int width, int height, int tile_rank, int tile_ranks, void* stream) {

@@ -109,6 +109,32 @@ def test_render_is_deterministic_and_tiles_compose(gpu_scenes, flat_scenes):
     assert np.array_equal(bits(full.cpu().numpy()), bits(a))
 
 
+def test_tiles_pack_gather_unpack_on_device(gpu_scenes, flat_scenes):
+    """The multi-GPU assembly (bench.py, raytracer_amd.distributed) on one device: every rank's tiles packed, unpacked into
+    the root's frame -- stream-ordered calls, no host synchronisation in between -- give the single-rank frame."""
+    import torch
+    import raytracer_amd as rt
+    from raytracer_amd import distributed as rd
+    fs = flat_scenes("c")
+    W, H, ranks = 200, 100, 3          # partial edge tiles, ragged tile counts
+    cam = rt.Camera(fs.fov, W, H)
+    sc = gpu_scenes("c")
+    whole = sc.render(W, H, camera=cam)
+    root = torch.zeros(H, W, 3, device="cuda")
+    for rank in range(ranks):
+        part = torch.full((H, W, 3), -1.0, device="cuda")
+        sc.render_into(part.data_ptr(), W, H, camera=cam, tile_rank=rank, tile_ranks=ranks)
+        n = sc.tiles_count(W, H, rank, ranks)
+        assert n == rd.tiles_count(W, H, rank, ranks)
+        packed = torch.zeros(n * 256 * 3, device="cuda")
+        sc.tiles_pack(part.data_ptr(), packed.data_ptr(), W, H, rank, ranks)
+        sc.tiles_unpack(packed.data_ptr(), root.data_ptr(), W, H, rank, ranks)
+        # the device's pack order is the one the CPU restatement (gloo tests) uses
+        ref = rd.pack_tiles(part.cpu(), rank, ranks)
+        assert np.array_equal(bits(packed.cpu().numpy().reshape(-1, 3)), bits(ref.numpy()))
+    assert np.array_equal(bits(root.cpu().numpy()), bits(whole))
+
+
 def test_queue_overflow_splits_batches(flat_scenes, monkeypatch):
     import raytracer_amd as rt
     monkeypatch.setenv("RT_QUEUE_RAYS", "4096")

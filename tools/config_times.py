@@ -10,7 +10,9 @@ def run(name, path, W, H, aa=(1, 1), max_depth=16, eye=(0, 0, 0), rot_x=0.0, rep
     t0 = time.perf_counter()
     flat = rt.FlatScene.load(path) if path.endswith(".rtscene") else rt.FlatScene.from_json(path)
     t_load = time.perf_counter() - t0
+    t0 = time.perf_counter()
     sc = rt.Scene(flat, 0)
+    t_up = time.perf_counter() - t0
     cam = rt.Camera(flat.fov, W, H, eye=eye, rot_x=rot_x)
     frame = torch.zeros(H, W, 3, device="cuda")
     sc.render_into(frame.data_ptr(), W, H, aa=aa, camera=cam, max_depth=max_depth)
@@ -19,7 +21,7 @@ def run(name, path, W, H, aa=(1, 1), max_depth=16, eye=(0, 0, 0), rot_x=0.0, rep
         st = sc.render_into(frame.data_ptr(), W, H, aa=aa, camera=cam, max_depth=max_depth)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
     rays = st["rays_nearest"] + st["rays_shadow"]
-    print(f"{name}: load {t_load:.1f} s, {dt * 1e3:.2f} ms/frame, {rays / 1e6:.1f} Mrays ({st['rays_nearest'] / 1e6:.1f} nearest), {rays / dt / 1e6:.0f} Mrays/s, levels {st['levels']}, splits {st['batch_splits']}", flush=True)
+    print(f"{name}: load {t_load:.1f} s, upload {t_up:.2f} s, {dt * 1e3:.2f} ms/frame, {rays / 1e6:.1f} Mrays ({st['rays_nearest'] / 1e6:.1f} nearest), {rays / dt / 1e6:.0f} Mrays/s, levels {st['levels']}, splits {st['batch_splits']}", flush=True)
     sc.close()
 
 only = os.environ.get("CONFIG", "")

@@ -60,6 +60,7 @@ struct rt_scene {
 	};
 	uint32_t qcap = 0;
 	int maxBlocks = 2048;            // grid cap of the persistent kernels
+	int maxBlocksPacketNear = 2048;  // ... of the nearest-hit packet kernel (see rt_scene_upload)
 	std::vector<Lane> lanes;
 	RtAccum accum{};
 	// Frames are rendered asynchronously: rt_render_submit queues one shard of the frame on every lane (shard k = the
@@ -473,7 +474,7 @@ struct Run {
 		for (int level = 0; level <= maxDepth && n > 0; level++) {
 			HIPCHK(hipMemsetAsync(ln->ctr, 0, RT_COUNTER_RESET_BYTES, st));   // queue counts and work cursors
 			if (timeK) HIPCHK(hipEventRecord(ln->ev[2], st));
-			rtk_intersect(st, sc->dev, sc->hasCsg, count, coherent(level), sc->maxBlocks, ln->ray[cur], n, ln->hitq, ln->ctr);
+			rtk_intersect(st, sc->dev, sc->hasCsg, count, coherent(level), coherent(level) ? sc->maxBlocksPacketNear : sc->maxBlocks, ln->ray[cur], n, ln->hitq, ln->ctr);
 			if (timeK) HIPCHK(hipEventRecord(ln->ev[3], st));
 			rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, n, ln->ray[cur ^ 1], ln->surfq, ln->transq, ln->ctr, sc->accum, aaSq, maxDepth,
 			          sc->shadowRaysPerSurface > 0, level == 0 ? src.outHit : nullptr, src.outId, src.outT);
@@ -700,6 +701,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	rt_scene* sc = new rt_scene();
 	sc->device = device;
 	sc->maxBlocks = std::max(1, prop.multiProcessorCount) * (int)std::max<uint32_t>(1, envU32("RT_BLOCKS_PER_CU", 8));
+	sc->maxBlocksPacketNear = std::max(1, prop.multiProcessorCount) * (int)std::max<uint32_t>(1, envU32("RT_BLOCKS_PER_CU_NEAR", 2));
 	auto fail = [&](int rc) { rt_scene_free(sc); return rc; };
 	DevScene& D = sc->dev;
 	int rc;

@@ -15,6 +15,9 @@
 #ifndef RT_PACKET_WAVES_PER_SIMD
 #define RT_PACKET_WAVES_PER_SIMD 5   /* register budget of the packet kernels: 512 / 5 -> 96 VGPRs (6 and 8 spill and are slower) */
 #endif
+#ifndef RT_AREA_WAVES_PER_SIMD
+#define RT_AREA_WAVES_PER_SIMD 4   /* register budget of k_shadow_area: 128 VGPRs (3: 10 % slower on C4, 5: spills, 60 % slower) */
+#endif
 #define RT_MAX_TREE_DEPTH 20   /* deepest reference tree accepted at upload (the reference's build stops at 16, bvh.h:6) */
 #define RT_STACK_DEPTH 32     /* traversal stack entries: per lane in LDS for the per-lane walk (32 x 256 x 4 B = 32 KB per
                                  workgroup), per wave for packets.  A nearer-child-first walk of a binary tree needs at most

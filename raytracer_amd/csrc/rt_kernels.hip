@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_shadow_poi
 // consecutive lanes (their rays leave the same point towards neighbouring targets), summed across lanes by a
 // segmented shuffle scan so each surface costs one atomic per wave instead of one per sample.
 template <bool CSG, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t seed,
+__global__ __launch_bounds__(kBlock, RT_AREA_WAVES_PER_SIMD) void k_shadow_area(DevScene S, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t seed,
                                                         RtAccum A, uint32_t aaSq, RtCounters* ctr) {
 	const PacketLds ws = packetLdsInit(S);
 	const rt_light L = S.lights[lightIndex];
@@ -1238,18 +1238,17 @@ __global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, 
 	const unsigned long long j = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
 	const bool live = j < (unsigned long long)nsurf * ns;
 	uint32_t s = kInactive;
-	f3 c = mk3(0, 0, 0);
-	Surface sf;
-	sf.w = c; sf.pixKey = 0;
+	f3 c = mk3(0, 0, 0), p = c;
 	Trav T;
 	T.cur = kEmpty; T.lit = true; T.shadow = mk3(1.0f, 1.0f, 1.0f); T.cntNodes = 0; T.cntPrims = 0;
 	f3 lightPos = c;
 	if (live) {
 		s = (uint32_t)(j / ns);
 		const uint32_t smp = (uint32_t)(j % ns);
-		sf = loadSurface(sq, s);
+		// only the surface point is held during the walk; the rest of the record is read when the sample turned out lit
+		p = mk3(qf(sq, SQ_PX, s), qf(sq, SQ_PY, s), qf(sq, SQ_PZ, s));
 		float r1, r2;
-		rng2(seed, sf.pixKey, sf.path, (uint32_t)lightIndex, smp, r1, r2);   // stands in for RAND, arealight.cpp:5
+		rng2(seed, qu(sq, SQ_PIX, s), qu(sq, SQ_PATH, s), (uint32_t)lightIndex, smp, r1, r2);   // stands in for RAND, arealight.cpp:5
 		float xDisplacement, yDisplacement;
 		if (L.type == RT_LIGHT_RECT) {   // arealight.cpp:37-42
 			xDisplacement = (float)(((double)r1 - 0.5) * (double)L.width);
@@ -1261,12 +1260,17 @@ __global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, 
 			yDisplacement = displacement * sinf(angle);
 		}
 		lightPos = ld3(L.position) + ld3(L.planeX) * xDisplacement + ld3(L.planeY) * yDisplacement;
-		travInit<true>(S, T, sf.p, lightPos - sf.p);
+		travInit<true>(S, T, p, lightPos - p);
 	}
 	packetTraverse<true, CSG, COUNT>(S, ws, T, live);
+	f3 w = mk3(0, 0, 0);
+	uint32_t pixKey = 0;
 	if (live) {
 		if (COUNT) { atomicAdd(&ctr->nodes_shadow, T.cntNodes); atomicAdd(&ctr->prims_shadow, T.cntPrims); }
-		if (T.lit) c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
+		if (T.lit) {
+			const Surface sf = loadSurface(sq, s);
+			c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
+		}
 	}
 	// segmented inclusive scan over the wave, key = surface
 	const uint32_t lane = __lane_id();
@@ -1277,7 +1281,11 @@ __global__ __launch_bounds__(kBlock) void k_shadow_area(DevScene S, RtQueue sq, 
 		if (lane >= (uint32_t)off && ks2 == s) { c.x += ax; c.y += ay; c.z += az; }
 	}
 	const uint32_t nextKey = __shfl_down(s, 1);
-	if (live && (lane == 63u || nextKey != s)) accumAdd(A, sf.pixKey / aaSq, sf.w * (c / (float)ns));   // arealight.cpp:21
+	if (live && (lane == 63u || nextKey != s)) {   // arealight.cpp:21
+		w = mk3(qf(sq, SQ_WR, s), qf(sq, SQ_WG, s), qf(sq, SQ_WB, s));
+		pixKey = qu(sq, SQ_PIX, s);
+		accumAdd(A, pixKey / aaSq, w * (c / (float)ns));
+	}
 }
 
 // shadowRay() for caller-supplied queries (rt_shadow_batch)

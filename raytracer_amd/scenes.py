@@ -227,6 +227,92 @@ def random_csg_scene(out_dir, seed=0, n_objects=24, max_leaves=16):
     return path
 
 
+def random_scene(out_dir, seed=0, n_objects=40):
+    """A random mix of everything the trace path handles, for fuzzing parity against the oracle: planes, spheres, boxes,
+    small and mid-size meshes (one of them textured, one a CSG operand), bump-mapped spheres, CSG trees; materials that
+    reflect, transmit (ior 0 / 1 / 1.33 / 1.5) or both; ambient, directional, point and spot lights and sometimes a
+    small area light."""
+    os.makedirs(out_dir, exist_ok=True)
+    rng = np.random.default_rng(1000 + seed)
+    write_bmp24(os.path.join(out_dir, "fz_tex.bmp"), tiles_texture(64, 4))
+    write_bmp24(os.path.join(out_dir, "fz_bump.bmp"), bump_texture(64, seed=seed + 1))
+
+    def vec(lo, hi):
+        return [_fmt(float(v)) for v in rng.uniform(lo, hi, 3)]
+
+    def material():
+        m = {"ambient": vec(0.0, 0.2), "diffuse": vec(0.1, 0.9)}
+        if rng.random() < 0.6:
+            m["specular"] = vec(0.1, 0.8); m["shininess"] = _fmt(float(rng.uniform(2, 60)))
+        r = rng.random()
+        if r < 0.25 or r > 0.9:
+            m["reflective"] = vec(0.1, 0.7)
+        if r > 0.7:
+            m["transmissive"] = vec(0.2, 0.8)
+            m["refraction"] = [0.0, 1.0, 1.33, 1.5][int(rng.integers(0, 4))]
+        return m
+
+    def blob(c, r, subdiv):
+        tris = icosphere(subdiv) * r * rng.uniform(0.7, 1.3, 3) + c
+        return [[[_fmt(float(x)) for x in v] for v in t] for t in tris]
+
+    def leaf(c, r):
+        k = rng.random()
+        o = rng.uniform(-0.5, 0.5, 3) * r
+        if k < 0.45:
+            return {"type": "sphere", "position": [_fmt(float(v)) for v in c + o], "radius": _fmt(float(rng.uniform(0.4, 0.9) * r))}
+        if k < 0.9:
+            h = rng.uniform(0.3, 0.8, 3) * r
+            return {"type": "box", "point1": [_fmt(float(v)) for v in c + o - h], "point2": [_fmt(float(v)) for v in c + o + h]}
+        return {"type": "mesh", "triangles": blob(c + o, 0.7 * r, 1)}
+
+    def tree(leaves, c, r):
+        if leaves == 1:
+            return leaf(c, r)
+        left = int(rng.integers(1, leaves))
+        return {"operation": str(rng.choice(["union", "intersection", "difference"])), "first": tree(left, c, r), "second": tree(leaves - left, c, r)}
+
+    objects = [{"type": "plane", "position": [0, -1.2, 0], "normal": [0, 1, 0], "material": material()}]
+    if rng.random() < 0.5:
+        objects.append({"type": "plane", "position": [0, 0, -14], "normal": [_fmt(float(rng.uniform(-0.3, 0.3))), 0, 1], "material": material()})
+    for _ in range(n_objects):
+        c = np.array([rng.uniform(-4, 4), rng.uniform(-0.9, 1.8), rng.uniform(-11, -3)])
+        r = float(rng.uniform(0.25, 0.8))
+        k = rng.random()
+        if k < 0.25:
+            o = {"type": "sphere", "position": [_fmt(float(v)) for v in c], "radius": _fmt(r)}
+        elif k < 0.4:
+            h = rng.uniform(0.4, 1.0, 3) * r
+            o = {"type": "box", "point1": [_fmt(float(v)) for v in c - h], "point2": [_fmt(float(v)) for v in c + h]}
+        elif k < 0.6:
+            o = {"type": "mesh", "triangles": blob(c, r, int(rng.integers(0, 3)))}
+        elif k < 0.68:
+            tris = blob(c, r, 1)
+            uv = [[[_fmt(float(u)) for u in rng.uniform(0, 1, 2)] for _ in range(3)] for _ in tris]
+            o = {"type": "texturemesh", "triangles": tris, "uvCoords": uv, "texture": "fz_tex.bmp"}
+        elif k < 0.75:
+            o = {"type": "bumpsphere", "position": [_fmt(float(v)) for v in c], "radius": _fmt(r), "bumpmap": "fz_bump.bmp", "bumpdepth": _fmt(float(rng.uniform(0.1, 0.6)))}
+        else:
+            o = {"type": "csgobject"}
+            o.update(tree(int(rng.integers(2, 9)), c, r))
+        o["material"] = material()
+        objects.append(o)
+    lights = [{"type": "ambient", "color": vec(0.1, 0.3)},
+              {"type": "directional", "color": vec(0.2, 0.6), "direction": [_fmt(float(rng.uniform(-0.6, 0.6))), -1.0, _fmt(float(rng.uniform(-0.6, 0.2)))]},
+              {"type": "point", "color": vec(0.2, 0.7), "position": [_fmt(float(rng.uniform(-3, 3))), _fmt(float(rng.uniform(2.5, 5))), _fmt(float(rng.uniform(-8, 0)))]}]
+    if rng.random() < 0.5:
+        lights.append({"type": "spot", "color": vec(0.3, 0.8), "position": [_fmt(float(rng.uniform(-3, 3))), 4.0, -2.0],
+                       "direction": [_fmt(float(rng.uniform(-0.3, 0.3))), -1.0, _fmt(float(rng.uniform(-1.0, -0.2)))], "cutoff": _fmt(float(rng.uniform(15, 50)))})
+    if rng.random() < 0.3:
+        lights.append({"type": "rectangular", "color": vec(0.2, 0.5), "position": [0.5, 4.5, -6.0], "normal": [0, -1, 0], "orientation": [1, 0, 0],
+                       "width": 1.0, "height": 0.6, "samples": 4})
+    scene = {"camera": {"field": 60, "background": vec(0.0, 0.3)}, "objects": objects, "lights": lights}
+    path = os.path.join(out_dir, f"random_{seed}.json")
+    with open(path, "w") as f:
+        json.dump(scene, f)
+    return path
+
+
 def c4_scene(out_dir, samples=64):
     """BASELINE config 4: a room with CSG furniture lit by a rectangular and a circular area light, `samples` each."""
     os.makedirs(out_dir, exist_ok=True)

@@ -313,6 +313,26 @@ def random_scene(out_dir, seed=0, n_objects=40):
     return path
 
 
+def awkward_rays(rng, n):
+    """Origins and directions for fuzzing the ray queries (tools/fuzz_rays.py): zero, denormal, tiny and huge direction
+    components, no direction at all, origins on round coordinates (box faces of the generators), diagonals."""
+    e = rng.uniform([-5, -1.5, -12], [5, 3, 2], (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    kind = rng.integers(0, 10, n)
+    for k in range(3):
+        d[(kind == 1) & (rng.random(n) < 0.5), k] = 0.0                    # axis-parallel
+    d[kind == 2] *= np.float32(1e-30)                                       # tiny
+    d[kind == 3] *= np.float32(1e20)                                        # huge
+    d[kind == 4, int(rng.integers(0, 3))] = np.float32(1e-42)               # a denormal component
+    d[kind == 5] = 0.0                                                      # no direction at all
+    e[kind == 6] = np.round(e[kind == 6] * 2) / 2                           # origins on a lattice (box faces of the generators use round numbers)
+    d[kind == 7] = np.sign(d[kind == 7]) * np.float32(1.0)                  # diagonals
+    d[kind == 8, 1] = -np.abs(d[kind == 8, 1])                              # towards the floor plane
+    neg0 = (kind == 9)
+    d[neg0, 0] = np.float32(-0.0)
+    return e, d
+
+
 def c4_scene(out_dir, samples=64):
     """BASELINE config 4: a room with CSG furniture lit by a rectangular and a circular area light, `samples` each."""
     os.makedirs(out_dir, exist_ok=True)

@@ -163,6 +163,26 @@ def test_random_mixed_scenes(tmp_path, seed):
     sc.close()
 
 
+def test_awkward_rays_on_a_random_scene(tmp_path):
+    """rt_intersect_batch / rt_shadow_batch with directions that have zero, denormal, tiny or huge components (the slab
+    test's 0 * inf cases), origins on box faces, lights at the shaded point (tools/fuzz_rays.py: 20 seeds agree)."""
+    flat = rt.FlatScene.from_json(scenes.random_scene(str(tmp_path), seed=3))
+    sc = rt.Scene(flat, 0)
+    rng = np.random.default_rng(3)
+    e, d = scenes.awkward_rays(rng, 60000)
+    r, o = sc.intersect_batch(e, d), oracle.intersect_batch(flat, e, d)
+    assert np.array_equal(r["hit"], o["hit"]) and np.array_equal(r["id"], o["id"]) and np.array_equal(bits(r["t"]), bits(o["t"]))
+    hit = o["hit"].astype(bool)
+    p = (e + o["t"][:, None] * d)[hit].astype(np.float32)
+    l = rng.uniform([-4, 2, -9], [4, 6, 1], (len(p), 3)).astype(np.float32)
+    l[::7] = p[::7]
+    rs, os_ = sc.shadow_batch(p, l), oracle.shadow_batch(flat, p, l)
+    assert np.array_equal(rs["lit"], os_["lit"])
+    lit = os_["lit"].astype(bool)
+    assert np.abs(rs["shadow"][lit] - os_["shadow"][lit]).max() < 1e-6
+    sc.close()
+
+
 def test_c4_area_lights_64_samples(tmp_path):
     flat = rt.FlatScene.from_json(scenes.c4_scene(str(tmp_path), samples=64))
     sc = rt.Scene(flat, 0)

@@ -104,6 +104,16 @@ __device__ __forceinline__ float triHit(f3 p0, f3 p1, f3 p2, f3 n, f3 e, f3 d, b
 	if (t <= 0 || !inside) return 0.0f;
 	return t;
 }
+// What Plane::rayhit's early return (objects.cpp:206) decides from signs alone, without the divide: with numerator = n.(p0 - e)
+// and denominator = n.d as the reference computes them, t = numerator / denominator is positive with numerator <= 0
+// only if both are negative (zero, NaN and -0 denominators all end in a miss further down).  A shadow query also needs
+// t < 1 to count (bvh.cpp:148), and for negative floats that is exactly numerator > denominator: the quotient of two
+// distinct floats is at most 1 - 2^-24 and rounds below 1.  False = the triangle cannot be a hit for this ray.
+template <bool ANYHIT>
+__device__ __forceinline__ bool triCandidate(f3 p0, f3 n, f3 e, f3 d) {
+	const float num = dot(n, p0 - e), den = dot(n, d);
+	return num < 0.0f && den < 0.0f && (!ANYHIT || num > den);
+}
 __device__ __forceinline__ float triHit(const rt_tri* tr, f3 e, f3 d, bool exitHit) {
 	// 64 B record: four 16 B loads
 	const float4* q = reinterpret_cast<const float4*>(tr);

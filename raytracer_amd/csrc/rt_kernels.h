@@ -15,6 +15,9 @@
 #ifndef RT_PACKET_WAVES_PER_SIMD
 #define RT_PACKET_WAVES_PER_SIMD 5   /* register budget of the packet kernels: 512 / 5 -> 96 VGPRs (6 and 8 spill and are slower) */
 #endif
+#ifndef RT_SHADOW_WAVES_PER_SIMD
+#define RT_SHADOW_WAVES_PER_SIMD 4   /* k_shadow_point_packet: 128 VGPRs (at 96 its triangle early-out spills inside the walk and costs more than it saves) */
+#endif
 #ifndef RT_AREA_WAVES_PER_SIMD
 #define RT_AREA_WAVES_PER_SIMD 4   /* register budget of k_shadow_area: 128 VGPRs (3: 10 % slower on C4, 5: spills, 60 % slower) */
 #endif

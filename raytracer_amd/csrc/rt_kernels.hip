@@ -282,7 +282,9 @@ __device__ __forceinline__ void travLeaf(const DevScene& S, Trav& T) {
 	for (uint32_t k = 0; k < count; k++) {
 		const float4* q = reinterpret_cast<const float4*>(tris + k);
 		const float4 a = q[0], b = q[1], c = q[2], d = q[3];
-		const float t = triHit(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), T.e, T.d, false);
+		float t = 0.0f;   // (what triHit returns when the plane test fails)
+		if (!ANYHIT || __ballot(triCandidate<ANYHIT>(mk3(a.x, a.y, a.z), mk3(c.y, c.z, c.w), T.e, T.d)) != 0)
+			t = triHit(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), T.e, T.d, false);
 		if (COUNT) T.cntPrims++;
 		const uint32_t index = embedded ? __float_as_uint(d.z) : first + k;
 		const uint32_t key = embedded ? __float_as_uint(d.w) : (uint32_t)~T.cur + 1u + k;
@@ -488,9 +490,18 @@ __device__ __forceinline__ void packetPrim(const DevScene& S, Trav& T, bool inSu
 // bvh.cpp:109-118 / 145-157 for a triangle whose record is already in registers (same in every lane)
 template <bool ANYHIT, bool COUNT>
 __device__ __forceinline__ void packetTri(const DevScene& S, Trav& T, bool inSub, float4 a, float4 b, float4 c, uint32_t index, int mat, uint32_t key) {
-	if (inSub && (!ANYHIT || T.lit)) {
+	const bool active = inSub && (!ANYHIT || T.lit);
+	if (COUNT && active) T.cntPrims++;
+	// Most tests end at the plane: a shadow ray leaving a surface looks at the back of the neighbouring triangles.  The
+	// signs of the plane test's two dot products say so before the fp64 divide and the three edge tests, and when no lane
+	// of the packet is left the wave skips them (exact: triCandidate, rt_device.h).
+	bool cand = active;
+	if (ANYHIT) {   // (camera rays mostly face what they test: nothing to gain there)
+		cand = active && triCandidate<ANYHIT>(mk3(a.x, a.y, a.z), mk3(c.y, c.z, c.w), T.e, T.d);
+		if (__ballot(cand) == 0) return;
+	}
+	if (cand) {
 		const float t = triHit(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), T.e, T.d, false);
-		if (COUNT) T.cntPrims++;
 		if (!ANYHIT) {
 			if ((double)t > 1e-5 && (t < T.tmin || (t == T.tmin && key < T.bestKey))) { T.best = RT_PRIM_REF(RT_PRIM_TRI, index); T.bestTag = 0; T.tmin = t; T.bestKey = key; }
 		} else if (t < 1.0f && (double)(t * T.len) > 1e-5) {
@@ -1170,7 +1181,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq,
 // Packet form of k_shadow_point for coherent surface sets: 64 consecutive surfaces towards the same light.  Only the
 // surface point is held during the walk; the rest of the surface record is read when the ray turned out lit.
 template <bool CSG, bool COUNT>
-__global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_shadow_point_packet(DevScene S, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
+__global__ __launch_bounds__(kBlock, RT_SHADOW_WAVES_PER_SIMD) void k_shadow_point_packet(DevScene S, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                                                                 RtAccum A, uint32_t aaSq, RtCounters* ctr) {
 	const uint32_t lane = __lane_id();
 	const PacketLds ws = packetLdsInit(S);

@@ -1,22 +1,27 @@
-// rt_kernels.hip -- the wavefront pipeline for gfx950 (MI355X): generate -> [intersect -> shade -> shadow]* -> resolve.
+// rt_kernels.hip -- the wavefront pipeline for gfx950 (MI355X): generate -> [intersect -> shade -> transmit -> shadow]* -> resolve.
 //
 // The reference evaluates one pixel at a time by mutual recursion (trace -> findNearest -> lightPoint -> trace /
 // shadowRay).  Here one LEVEL of the ray tree of a whole batch of pixels is processed per
 // iteration: rays live in SoA queues in HBM (component c of slot i at base[c*cap + i], so a wave's 64 lanes read
 // 256 contiguous bytes per component), child rays are appended to the next level's queue through one atomic per
-// wave (ballot + prefix popcount), and the recursion's colour arithmetic becomes a per-ray RGB weight: the
+// wave or workgroup (ballot + prefix popcount), and the recursion's colour arithmetic becomes a per-ray RGB weight: the
 // reference's combine  C = (1-kt)*(kr*C_refl + sum lights) + kt*C_trans  (objects.cpp:60-104) is linear in the
 // child colours.  Pixel sums are accumulated in 32.32 fixed point with integer atomics, which is associative, so
 // the image does not depend on the order in which waves retire.
 //
-// Kernels (all 256-thread blocks = 4 waves):
-//   k_generate      q1.cpp:51-64 primary rays, in 8x8-pixel blocks per wave inside 32x8 tiles
-//   k_intersect     BVH::findNearest bvh.cpp:72-121; per-lane traversal stack in LDS, nearer child first
-//   k_shade         Object::lightPoint objects.cpp:54-105 minus the shadow rays: normals (bump.cpp), textures
-//                   (texturemesh.cpp), ambient term, reflection / transmission children (transmitRay)
-//   k_shadow_point  Directional/Point/Spot::lightPoint objects.cpp:399-458 -> BVH::calcShadow bvh.cpp:123-160
-//   k_shadow_area   AreaLight::lightPoint arealight.cpp:7-22, one lane per sample, segmented wave reduction
-//   k_resolve       fixed point -> float RGB (+ the /4 of q1.cpp:140 for supersampling)
+// Kernels (256-thread blocks = 4 waves unless noted):
+//   k_generate              q1.cpp:51-64 primary rays, in 8x8-pixel blocks per wave inside 32x8 tiles
+//   k_intersect_packet      BVH::findNearest bvh.cpp:72-121 for coherent rays (level 0 of a frame): 64 rays walk the union
+//                           of their subtrees over treelets staged in LDS (packetTraverse)
+//   k_intersect             ... for incoherent rays (deeper levels, caller-supplied batches): persistent per-lane walk,
+//                           per-lane stack in LDS, nearer child first (travRound)
+//   k_shade                 Object::lightPoint objects.cpp:54-105 minus the shadow rays: normals (bump.cpp), textures
+//                           (texturemesh.cpp), ambient term, reflected children, requests for transmitted children
+//   k_transmit              Object::transmitRay objects.cpp:107-140 over the compacted requests (64-thread blocks)
+//   k_shadow_point_packet,  Directional/Point/Spot::lightPoint objects.cpp:399-458 -> BVH::calcShadow bvh.cpp:123-160,
+//   k_shadow_point          packet and per-lane form
+//   k_shadow_area           AreaLight::lightPoint arealight.cpp:7-22, one lane per sample, segmented wave reduction
+//   k_resolve               fixed point -> float RGB (+ the /4 of q1.cpp:140 for supersampling)
 #include "rt_kernels.h"
 #include "rt_device.h"
 #include <algorithm>

@@ -648,19 +648,19 @@ constexpr uint32_t kPacketGroup = 8;
 #define RT_PACKET_CHUNK 1
 #endif
 constexpr uint32_t kPacketChunk = RT_PACKET_CHUNK;   // packets per cursor atomic (divides kPacketGroup); 2 and 4 measured slower: the statically handed-out share grows with it and unbalances the launch
-struct WorkPool { uint32_t next, end; bool drained; };
+struct WorkPool { uint32_t next, end, chunk; bool drained; };
 
 __device__ __forceinline__ uint32_t fetchWork(bool need, WorkPool& pool, uint32_t* head, unsigned long long total) {
 	const unsigned long long mask = __ballot(need);
 	if (mask == 0) return kInactive;
 	if (pool.next == pool.end && !pool.drained) {   // wave-uniform
 		uint32_t base = 0;
-		if (__lane_id() == 0) base = atomicAdd(head, kWorkChunk);
-		const unsigned long long b = (unsigned long long)__builtin_amdgcn_readfirstlane(base) + (unsigned long long)waveCount() * kWorkChunk;
+		if (__lane_id() == 0) base = atomicAdd(head, pool.chunk);
+		const unsigned long long b = (unsigned long long)__builtin_amdgcn_readfirstlane(base) + (unsigned long long)waveCount() * pool.chunk;
 		if (b >= total) pool.drained = true;
 		else {
 			pool.next = (uint32_t)b;
-			pool.end = (uint32_t)(b + kWorkChunk < total ? b + kWorkChunk : total);
+			pool.end = (uint32_t)(b + pool.chunk < total ? b + pool.chunk : total);
 		}
 	}
 	const uint32_t avail = pool.end - pool.next;
@@ -672,11 +672,15 @@ __device__ __forceinline__ uint32_t fetchWork(bool need, WorkPool& pool, uint32_
 }
 // every wave starts on the chunk with its own number (no cursor stampede at launch, see fetchPacket)
 __device__ __forceinline__ WorkPool firstPool(unsigned long long total) {
-	const unsigned long long b = (unsigned long long)waveNumber() * kWorkChunk;
+	// a launch that does not fill the chip twice hands every wave one wave's worth: small levels of a deep ray tree end with
+	// their slowest lane, and two rounds of 64 on half of the waves take twice as long as one round on all of them
+	const uint32_t chunk = total <= (unsigned long long)waveCount() * 64u ? 64u : kWorkChunk;
+	const unsigned long long b = (unsigned long long)waveNumber() * chunk;
 	WorkPool p;
+	p.chunk = chunk;
 	p.drained = false;
 	p.next = (uint32_t)(b < total ? b : total);
-	p.end = (uint32_t)(b + kWorkChunk < total ? b + kWorkChunk : total);
+	p.end = (uint32_t)(b + chunk < total ? b + chunk : total);
 	if (p.end < p.next) p.end = p.next;
 	return p;
 }

@@ -69,14 +69,14 @@ enum { TQ_PRIM, TQ_PX, TQ_PY, TQ_PZ, TQ_DX, TQ_DY, TQ_DZ, TQ_NX, TQ_NY, TQ_NZ, T
 #define RT_PROF 0
 #endif
 #define RT_TRACE_LEN 2048
-#define RT_COUNTER_RESET_BYTES (6 * 4)
+#define RT_COUNTER_RESET_BYTES (8 * 4)   /* 32 B: one fill kernel (24 B took the runtime two) */
 struct RtCounters {
 	uint32_t next_count;      // rays appended to the next level's queue
 	uint32_t surf_count;      // surface records appended
 	uint32_t head_nearest;    // work cursors of the persistent kernels
 	uint32_t head_shadow;
 	uint32_t trans_count;     // transmission requests appended by k_shade, consumed by k_transmit
-	uint32_t reserved;        // ---- everything above is reset at the start of every level (RT_COUNTER_RESET_BYTES) ----
+	uint32_t reserved[3];     // ---- everything above is reset at the start of every level (RT_COUNTER_RESET_BYTES) ----
 	uint32_t overflow;        // an append found its queue full (the batch is re-run in halves)
 	uint32_t pad;
 	unsigned long long nodes_nearest, prims_nearest;   // RT_FLAG_COUNTERS: 64 B nodes read / primitive tests in k_intersect

@@ -790,16 +790,17 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 void rt_scene_free(rt_scene* sc) {
 	if (!sc) return;
 	(void)hipSetDevice(sc->device);
-	for (void* p : sc->allocs) (void)hipFree(p);
-	if (sc->accum.rgb) (void)hipFree(sc->accum.rgb);
-	if (sc->accum.nonfinite) (void)hipFree(sc->accum.nonfinite);
-	{
+	{   // frames still in flight finish first: the lanes' workers use everything freed below
 		std::unique_lock<std::mutex> g(sc->mtx);
 		sc->drainLocked(g);
 		sc->stopping = true;
 	}
 	sc->cvWork.notify_all();
 	for (auto& t : sc->workers) t.join();
+	(void)hipDeviceSynchronize();
+	for (void* p : sc->allocs) (void)hipFree(p);
+	if (sc->accum.rgb) (void)hipFree(sc->accum.rgb);
+	if (sc->accum.nonfinite) (void)hipFree(sc->accum.nonfinite);
 	for (auto& ln : sc->lanes) {
 		if (ln.ctrHost) (void)hipHostFree(ln.ctrHost);
 		for (auto& ev : ln.ev) if (ev) (void)hipEventDestroy(ev);

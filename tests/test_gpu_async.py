@@ -79,3 +79,18 @@ def test_ticket_rules(c2):
     with pytest.raises(RtError):
         sc.render_wait(12345)
     assert all(torch.equal(bufs[0], b) for b in bufs[1:4])
+
+
+def test_handle_freed_with_frames_in_flight(c2):
+    """rt_scene_free with submitted, un-waited frames: the lanes finish them before anything they use is released."""
+    flat, _ = c2
+    W, H = 960, 540
+    cam = rt.Camera(flat.fov, W, H, eye=(0, 1.5, 1.0), rot_x=-0.3)
+    for _ in range(3):
+        sc = rt.Scene(flat, 0)
+        bufs = [torch.zeros(H, W, 3, device="cuda") for _ in range(3)]
+        for b in bufs:
+            sc.render_submit(b.data_ptr(), W, H, camera=cam)
+        sc.close()
+        torch.cuda.synchronize()
+        assert torch.equal(bufs[0], bufs[1]) and torch.equal(bufs[0], bufs[2]) and float(bufs[0].abs().sum()) > 0

@@ -333,6 +333,37 @@ def awkward_rays(rng, n):
     return e, d
 
 
+def scale_scene(path, factor):
+    """Writes a copy of a scene JSON with every length multiplied by `factor` (positions, radii, boxes, triangles, area-light
+    sizes) and returns its path: the same picture from a camera scaled alike, with the reference's absolute epsilons
+    (1e-5 acceptance thresholds, offsets of secondary rays) now large or small against the geometry."""
+    with open(path) as f:
+        scene = json.load(f)
+
+    def walk(o):
+        if isinstance(o, dict):
+            for k, v in list(o.items()):
+                if k in ("position", "point1", "point2", "triangles"):
+                    o[k] = mul(v)
+                elif k in ("radius", "width", "height") and isinstance(v, (int, float)):
+                    o[k] = v * factor
+                else:
+                    walk(v)
+        elif isinstance(o, list):
+            for v in o:
+                walk(v)
+
+    def mul(v):
+        return [mul(x) for x in v] if isinstance(v, list) else v * factor
+
+    walk(scene.get("objects", []))
+    walk(scene.get("lights", []))
+    out = path[:-5] + f"_x{factor:g}.json"
+    with open(out, "w") as f:
+        json.dump(scene, f)
+    return out
+
+
 def c4_scene(out_dir, samples=64):
     """BASELINE config 4: a room with CSG furniture lit by a rectangular and a circular area light, `samples` each."""
     os.makedirs(out_dir, exist_ok=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fuzzing the trace path against the oracle: random scenes (raytracer_amd.scenes.random_scene), a 256x144 frame of
 camera rays through rt_trace_batch and through the frame path, compared with the CPU restatement.
-usage: tools/fuzz_parity.py [first_seed] [count] [objects per scene]       (needs a GPU; prints one line per seed and a summary)"""
+usage: tools/fuzz_parity.py [first_seed] [count] [objects per scene] [scale of all lengths]       (needs a GPU; prints one line per seed and a summary)"""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -20,11 +20,12 @@ def rgb8(rgb):
     return (q * np.float32(255) + np.float32(0.5)).astype(np.uint8)
 
 
-def one(seed, W=256, H=144, depth=6, n_objects=40):
+def one(seed, W=256, H=144, depth=6, n_objects=40, scale=1.0):
     with tempfile.TemporaryDirectory() as tmp:
-        flat = rt.FlatScene.from_json(scenes.random_scene(tmp, seed=seed, n_objects=n_objects))
+        path = scenes.random_scene(tmp, seed=seed, n_objects=n_objects)
+        flat = rt.FlatScene.from_json(path if scale == 1.0 else scenes.scale_scene(path, scale))
     sc = rt.Scene(flat, 0)
-    cam = rt.Camera(flat.fov, W, H, eye=(0, 1.0, 1.5), rot_x=-0.2)
+    cam = rt.Camera(flat.fov, W, H, eye=(0, 1.0 * scale, 1.5 * scale), rot_x=-0.2)
     s = oracle.primary_targets(cam, W, H)
     e = np.tile(np.array(cam.c.eye[:], np.float32), (W * H, 1))
     r = sc.trace_batch(e, s, max_depth=depth, seed=7)
@@ -57,9 +58,10 @@ if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     n_objects = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+    scale = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
     bad = 0
     for seed in range(first, first + count):
-        r = one(seed, n_objects=n_objects)
+        r = one(seed, n_objects=n_objects, scale=scale)
         ok = r["ids"] and r["t"] and r["rays"] and r["rgb_bad"] < 2e-3 and r["frame_vs_batch"] < 1e-6
         bad += not ok
         print(f"seed {seed}: {'ok ' if ok else 'BAD'} ids {r['ids']} t {r['t']} rays {r['rays']} rgb>1/255 {r['rgb_bad']:.5f} frame==batch {r['frame_eq_batch']} "

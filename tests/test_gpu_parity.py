@@ -147,3 +147,22 @@ def test_queue_overflow_splits_batches(flat_scenes, monkeypatch):
     assert np.array_equal(bits(a), bits(b))
     assert small.last_stats["rays_nearest"] == big.last_stats["rays_nearest"]
     small.close(); big.close()
+
+
+@pytest.mark.parametrize("W,H,aa", [(1, 1, 1), (33, 9, 1), (500, 1, 1), (1, 70, 2), (40, 24, 4)])
+def test_odd_frame_shapes(W, H, aa, gpu_scenes, flat_scenes):
+    """Frames smaller than a tile, one pixel wide or high, with up to 16 samples per pixel; shards that own no tile at all."""
+    import torch
+    import raytracer_amd as rt
+    fs = flat_scenes("c")
+    sc = gpu_scenes("c")
+    cam = rt.Camera(fs.fov, W, H)
+    img = sc.render(W, H, aa=aa, camera=cam)
+    ref, nn, ns = oracle.render(fs, cam, W, H, aa=aa, seed=1, threads=4)
+    assert img.shape == (H, W, 3)
+    assert np.abs(rgb8(img).astype(int) - rgb8(ref).astype(int)).max() <= 1
+    assert sc.last_stats["rays_nearest"] == nn and sc.last_stats["rays_shadow"] == ns
+    full = torch.zeros(H, W, 3, device="cuda")
+    for rank in range(5):                                  # more ranks than tiles for the small frames
+        sc.render_into(full.data_ptr(), W, H, aa=aa, camera=cam, tile_rank=rank, tile_ranks=5)
+    assert np.array_equal(bits(full.cpu().numpy()), bits(img))

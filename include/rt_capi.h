@@ -131,6 +131,30 @@ int rt_render_host(rt_scene* scene, const rt_camera* camera, int width, int heig
 int rt_trace_batch(rt_scene* scene, const float* e, const float* s, size_t n, int max_depth, uint32_t seed, uint32_t flags,
                    uint8_t* hit, int32_t* obj_id, float* t, float* rgb, rt_stats* stats);
 
+/* trace(e, s, colour, pick = true) (raytracer.cpp:307-327): the one ray is traced like rt_trace_batch traces it, and what the
+ * reference would narrate on std::cout on the way -- "object ... hit at", "reflection:", "interior reflection at",
+ * "exit object at", ... (objects.cpp:54-140) -- comes back as events, in no particular order; rt_pick_narration puts them into
+ * the reference's order (depth first: a hit, its reflected ray, its transmitted ray) and words.  `n_events` receives the
+ * number of events the ray tree produced; more than `cap` means the list was cut. */
+typedef struct rt_pick_event {
+	uint32_t path;      /* the ray's position in the ray tree: 1 = the picked ray, 2p = the reflection of p, 2p + 1 = its transmission */
+	int32_t  kind;      /* RT_PICK_* */
+	int32_t  arg;       /* RT_PICK_HIT: RT_PRIM_* type of the object; RT_PICK_INTERIOR: number of the internal reflection (0 ..) */
+	int32_t  flags;     /* RT_PICK_HIT: bit 0 = the material reflects, bit 1 = it transmits */
+	float    p[3];      /* hit point / reflection point / exit point */
+} rt_pick_event;
+enum { RT_PICK_HIT = 1,        /* "object <type> hit at {p}"                          raytracer.cpp:323-324 */
+       RT_PICK_MISS = 2,       /* the ray `path` (> 1) hit nothing: "no additional objects hit"   objects.cpp:71-72, 97-98 */
+       RT_PICK_MAXDEPTH = 3,   /* the ray `path` was not traced: "Maximum number of reflections reached."  raytracer.cpp:308-313 */
+       RT_PICK_INTERIOR = 4,   /* "interior reflection at {p}"                        objects.cpp:129-131 */
+       RT_PICK_EXIT = 5,       /* "exit object at {p}"                                objects.cpp:90-92 */
+       RT_PICK_LOST = 6 };     /* "ray lost due to too many internal reflections"     objects.cpp:100-101 */
+int rt_trace_pick(rt_scene* scene, const float* e, const float* s, int max_depth, uint32_t seed,
+                  uint8_t* hit, float* rgb, rt_pick_event* events, size_t cap, size_t* n_events);
+/* The narration as text, one line per std::endl of the reference.  Returns the length of the whole text (without the
+ * terminating NUL); at most cap - 1 characters are written to buf. */
+size_t rt_pick_narration(const rt_pick_event* events, size_t n, char* buf, size_t cap);
+
 /* BVH::findNearest() for n rays (bvh.h:23, bvh.cpp:72-92): origin e[i], direction d[i] as given. */
 int rt_intersect_batch(rt_scene* scene, const float* e, const float* d, size_t n, uint32_t flags,
                        uint8_t* hit, int32_t* obj_id, float* t, rt_stats* stats);

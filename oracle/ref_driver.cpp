@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <iostream>
 #include <map>
 #include <vector>
 #include <string>
@@ -126,6 +127,22 @@ int main(int argc, char** argv) {
 	float rotX = 0, rotY = 0;
 	eye = point3(0, 0, 0);
 	if (argc > 11) { eye = point3(atof(argv[7]), atof(argv[8]), atof(argv[9])); rotX = atof(argv[10]); rotY = atof(argv[11]); }
+
+	// pick mode: ref_driver <scene> <W> <H> pick x y [x y ...] -- the reference's own narration of trace(..., pick = true)
+	// (raytracer.cpp:307-327, objects.cpp:54-140) for those pixels, on stdout, one "== pixel x y" header each
+	if (strcmp(outPath, "pick") == 0) {
+		eye = point3(0, 0, 0);   // (the optional camera arguments above are pixel coordinates in this mode)
+		choose_scene(sceneName);
+		setFacing(0, 0);
+		for (int a = 5; a + 1 < argc; a += 2) {
+			int x = atoi(argv[a]), y = atoi(argv[a + 1]);
+			std::cout << "== pixel " << x << " " << y << std::endl;
+			colour3 colour(0, 0, 0);
+			bool h = trace(eye, s_grid(x, y, 1, 0), colour, true);
+			std::cout << "== " << (h ? "hit" : "miss") << std::endl;
+		}
+		return 0;
+	}
 
 	choose_scene(sceneName);
 	build_ids();

@@ -144,6 +144,21 @@ class Scene:
         self.last_stats = st.as_dict()
         return dict(hit=hit, id=oid, t=t, rgb=rgb)
 
+    def trace_pick(self, e, s, max_depth=capi.MAX_REFLECTIONS, seed=1, cap=1 << 16):
+        """trace(e, s, colour, pick=True) (raytracer.cpp:307-327): returns (hit, rgb, narration) -- the text the reference
+        prints on std::cout for the picked ray, from the events the kernels record (rt_trace_pick / rt_pick_narration)."""
+        e, s = f32(e, (3,)), f32(s, (3,))
+        hit, rgb = np.zeros(1, np.uint8), np.zeros(3, np.float32)
+        ev = (capi.rt_pick_event * cap)()
+        n = C.c_size_t(0)
+        lib = capi.load()
+        check(lib.rt_trace_pick(self._h, ptr(e), ptr(s), max_depth, seed, ptr(hit), ptr(rgb), C.cast(ev, C.c_void_p), cap, C.byref(n)))
+        m = min(n.value, cap)
+        size = lib.rt_pick_narration(C.cast(ev, C.c_void_p), m, None, 0) + 1
+        buf = C.create_string_buffer(size)
+        lib.rt_pick_narration(C.cast(ev, C.c_void_p), m, buf, size)
+        return bool(hit[0]), rgb, buf.value.decode()
+
     def intersect_batch(self, e, d, flags=0):
         """BVH::findNearest for n rays (bvh.cpp:72): returns dict(hit, id, t)."""
         e, d = f32(e, (-1, 3)), f32(d, (-1, 3))
@@ -216,7 +231,13 @@ def current_scene():
 def trace(e, s, pick=False, reflectionCount=0):
     """trace(e, s, colour, pick, reflectionCount) -> (hit, colour); colour is None on a miss (left untouched in the reference)."""
     if reflectionCount > capi.MAX_REFLECTIONS:
+        if pick:
+            print("Maximum number of reflections reached.")
         return False, np.zeros(3, np.float32)
+    if pick:   # the reference's narration of the picked ray, on stdout
+        hit, rgb, text = current_scene().trace_pick(e, s, max_depth=capi.MAX_REFLECTIONS - max(reflectionCount, 0))
+        print(text, end="")
+        return (True, rgb) if hit else (False, None)
     r = current_scene().trace_batch(np.asarray(e, np.float32)[None], np.asarray(s, np.float32)[None],
                                     max_depth=capi.MAX_REFLECTIONS - max(reflectionCount, 0))
     if not r["hit"][0]:

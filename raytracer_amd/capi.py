@@ -19,9 +19,13 @@ MAX_REFLECTIONS = 16
 SYMBOLS = [
     "rt_load_scene_json", "rt_load_scene_json_text", "rt_flat_scene_save", "rt_flat_scene_load", "rt_flat_scene_free",
     "rt_camera_setup", "rt_write_bmp", "rt_quantize_rgb8", "rt_device_count", "rt_scene_upload", "rt_scene_free",
-    "rt_render", "rt_render_submit", "rt_render_wait", "rt_render_host", "rt_trace_batch", "rt_intersect_batch", "rt_shadow_batch", "rt_tiles_merge",
+    "rt_render", "rt_render_submit", "rt_render_wait", "rt_render_host", "rt_trace_batch", "rt_trace_pick", "rt_pick_narration", "rt_intersect_batch", "rt_shadow_batch", "rt_tiles_merge",
     "rt_tiles_count", "rt_tiles_pack", "rt_tiles_unpack", "rt_last_error", "rt_version",
 ]
+
+
+class rt_pick_event(C.Structure):
+    _fields_ = [("path", C.c_uint32), ("kind", C.c_int32), ("arg", C.c_int32), ("flags", C.c_int32), ("p", C.c_float * 3)]
 
 
 class RtError(RuntimeError):
@@ -94,6 +98,9 @@ def load():
                                    C.c_void_p, C.POINTER(rt_stats)]
     lib.rt_trace_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]
+    lib.rt_trace_pick.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.rt_pick_narration.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    lib.rt_pick_narration.restype = C.c_size_t
     lib.rt_intersect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]
     lib.rt_shadow_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]
     for name in ("rt_tiles_pack", "rt_tiles_unpack", "rt_tiles_merge"):

@@ -5,8 +5,12 @@
 #include "bmp_io.h"
 #include "host_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
+#include <map>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -141,3 +145,52 @@ int rt_write_bmp(const char* path, const float* rgb, int width, int height) {
 }
 
 }  // extern "C"
+
+// The reference narrates a picked ray on std::cout while it recurses (raytracer.cpp:307-327, objects.cpp:54-140): a hit,
+// then the reflected ray's whole story, then -- after the lights -- the transmitted ray's.  The device produces the same
+// facts level by level; here they are put back into that depth-first order, in the reference's words.  Numbers go through
+// an ostream like the reference's (6 significant digits).
+extern "C" size_t rt_pick_narration(const rt_pick_event* events, size_t n, char* buf, size_t cap) {
+	std::map<uint32_t, std::vector<const rt_pick_event*>> byPath;
+	for (size_t i = 0; i < n; i++) byPath[events[i].path].push_back(&events[i]);
+	auto find = [&](uint32_t path, int kind) -> const rt_pick_event* {
+		auto it = byPath.find(path);
+		if (it == byPath.end()) return nullptr;
+		for (const rt_pick_event* e : it->second) if (e->kind == kind) return e;
+		return nullptr;
+	};
+	static const char* const typeNames[] = { "sphere", "triangle", "box", "csgobject", "plane" };   // Object::type, by RT_PRIM_*
+	std::ostringstream out;
+	auto point = [&](const float* p) { out << "{" << p[0] << ", " << p[1] << ", " << p[2] << "}"; };
+	std::function<bool(uint32_t)> ray = [&](uint32_t path) -> bool {   // trace(): false = the caller reports the miss
+		if (find(path, RT_PICK_MAXDEPTH)) { out << "Maximum number of reflections reached." << "\n"; return false; }
+		const rt_pick_event* h = find(path, RT_PICK_HIT);
+		if (!h) return false;
+		out << "object " << (h->arg >= 0 && h->arg <= 4 ? typeNames[h->arg] : "object") << " hit at "; point(h->p); out << "\n";
+		if (h->flags & 1) {   // objects.cpp:62-75
+			out << "reflection:" << "\n";
+			if (!ray(path * 2u)) out << "no additional objects hit" << "\n";
+		}
+		if (h->flags & 2) {   // objects.cpp:81-104
+			out << "transmission:" << "\n";
+			std::vector<const rt_pick_event*> inner;
+			for (const rt_pick_event* e : byPath[path]) if (e->kind == RT_PICK_INTERIOR) inner.push_back(e);
+			std::sort(inner.begin(), inner.end(), [](const rt_pick_event* a, const rt_pick_event* b) { return a->arg < b->arg; });
+			for (const rt_pick_event* e : inner) { out << "interior reflection at "; point(e->p); out << "\n"; }
+			if (const rt_pick_event* x = find(path, RT_PICK_EXIT)) {
+				out << "exit object at "; point(x->p); out << "\n";
+				if (!ray(path * 2u + 1u)) out << "no additional objects hit" << "\n";
+			} else out << "ray lost due to too many internal reflections" << "\n";
+		}
+		return true;
+	};
+	ray(1u);
+	const std::string text = out.str();
+	if (buf && cap > 0) {
+		const size_t m = std::min(text.size(), cap - 1);
+		memcpy(buf, text.data(), m);
+		buf[m] = 0;
+	}
+	return text.size();
+}
+

@@ -1,13 +1,16 @@
 // raytracer_api.cpp -- the reference's Raytracer API (raytracer.h:12-18, raytracer.cpp:24-32,111-133,307-329) on top
 // of the C-ABI: a process-global scene, choose_scene() with the reference's messages and exit(EXIT_FAILURE) on a
-// missing file, and single-ray trace()/shadowRay() served by the GPU (batches of one).  No CPU path is involved.
+// missing file, and single-ray trace()/shadowRay() served by the GPU (batches of one; trace(..., pick = true) narrates like the reference does).
+// No CPU path is involved.
 #include "rt_capi.h"
 #include "host_internal.h"
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <iostream>
 #include <string>
+#include <vector>
 
 namespace {
 const char* PATH = "scenes/";   // raytracer.cpp:22
@@ -16,14 +19,6 @@ float g_background[3] = { 0, 0, 0 };
 rt_flat_scene* g_flat = nullptr;
 rt_scene* g_scene = nullptr;
 
-const char* typeName(const rt_flat_scene* s, int id) {
-	// names as Object::type holds them (objects.cpp:150,196,236,332; csg.cpp:5)
-	for (int i = 0; i < s->n_planes; i++) if (s->planes[i].id == id) return "plane";
-	for (int i = 0; i < s->n_spheres; i++) if (s->spheres[i].id == id) return "sphere";
-	for (int i = 0; i < s->n_boxes; i++) if (s->boxes[i].id == id) return "box";
-	for (int i = 0; i < s->n_csgs; i++) if (s->csgs[i].id == id) return "csgobject";
-	return "triangle";
-}
 }  // namespace
 
 extern "C" {
@@ -70,15 +65,22 @@ int rtapi_trace(const float* e, const float* s, float* colour, int pick, int ref
 		colour[0] = colour[1] = colour[2] = 0;
 		return 0;
 	}
-	uint8_t hit = 0; int32_t id = -1; float t = 0, rgb[3] = { 0, 0, 0 };
-	int rc = rt_trace_batch(g_scene, e, s, 1, RT_MAX_REFLECTIONS - (reflectionCount > 0 ? reflectionCount : 0), 1, 0, &hit, &id, &t, rgb, nullptr);
+	const int depth = RT_MAX_REFLECTIONS - (reflectionCount > 0 ? reflectionCount : 0);
+	uint8_t hit = 0; float rgb[3] = { 0, 0, 0 };
+	int rc;
+	if (pick) {   // the narration of raytracer.cpp:323-324 and objects.cpp:54-140, from the events the kernels leave
+		std::vector<rt_pick_event> ev(1u << 16);
+		size_t n = 0;
+		rc = rt_trace_pick(g_scene, e, s, depth, 1, &hit, rgb, ev.data(), ev.size(), &n);
+		if (rc == RT_OK) {
+			n = std::min(n, ev.size());
+			std::string text(rt_pick_narration(ev.data(), n, nullptr, 0) + 1, '\0');
+			rt_pick_narration(ev.data(), n, &text[0], text.size());
+			std::cout << text.c_str() << std::flush;
+		}
+	} else rc = rt_trace_batch(g_scene, e, s, 1, depth, 1, 0, &hit, nullptr, nullptr, rgb, nullptr);
 	if (rc != RT_OK) { std::cerr << "raytracer_amd: " << rt_last_error() << std::endl; abort(); }
 	if (!hit) return 0;   // colour untouched on a miss, like the reference
-	if (pick) {   // raytracer.cpp:323-324 (the deeper narration of objects.cpp is not reproduced)
-		float p[3];
-		for (int i = 0; i < 3; i++) p[i] = e[i] + t * (s[i] - e[i]);
-		std::cout << "object " << typeName(g_flat, id) << " hit at {" << p[0] << ", " << p[1] << ", " << p[2] << "}" << std::endl;
-	}
 	colour[0] = rgb[0]; colour[1] = rgb[1]; colour[2] = rgb[2];
 	return 1;
 }

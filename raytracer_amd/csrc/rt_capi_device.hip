@@ -449,6 +449,7 @@ struct Source {
 struct Run {
 	rt_scene* sc; rt_scene::Lane* ln; hipStream_t st; Source src; int maxDepth; uint32_t seed; uint32_t flags; uint32_t aaSq;
 	rt_stats stats{};
+	RtPick pick{ nullptr, nullptr, 0 };   // rt_trace_pick: where the narration's events go
 
 	// Which traversal form a level uses.  Level 0 of a frame (and its shadow rays) is coherent by construction: 64
 	// consecutive queue slots are an 8x8 pixel block.  Deeper levels and caller-supplied rays are walked per lane.
@@ -477,8 +478,8 @@ struct Run {
 			rtk_intersect(st, sc->dev, sc->hasCsg, count, coherent(level), coherent(level) ? sc->maxBlocksPacketNear : sc->maxBlocks, ln->ray[cur], n, ln->hitq, ln->ctr);
 			if (timeK) HIPCHK(hipEventRecord(ln->ev[3], st));
 			rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, n, ln->ray[cur ^ 1], ln->surfq, ln->transq, ln->ctr, sc->accum, aaSq, maxDepth,
-			          sc->shadowRaysPerSurface > 0, level == 0 ? src.outHit : nullptr, src.outId, src.outT);
-			if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, n, ln->ray[cur ^ 1], ln->ctr, sc->accum, aaSq, maxDepth);
+			          sc->shadowRaysPerSurface > 0, level == 0 ? src.outHit : nullptr, src.outId, src.outT, pick);
+			if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, n, ln->ray[cur ^ 1], ln->ctr, sc->accum, aaSq, maxDepth, pick);
 			if (int rc = syncCounters()) return rc;
 			if (timeK) {
 				float ms = 0;
@@ -945,6 +946,43 @@ int rt_trace_batch(rt_scene* sc, const float* e, const float* s, size_t n, int m
 	if (obj_id) HIPCHK(hipMemcpy(obj_id, did.p, n * 4, hipMemcpyDeviceToHost));
 	if (t) HIPCHK(hipMemcpy(t, dt.p, n * 4, hipMemcpyDeviceToHost));
 	if (rgb) HIPCHK(hipMemcpy(rgb, drgb.p, n * 12, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_trace_pick(rt_scene* sc, const float* e, const float* s, int max_depth, uint32_t seed, uint8_t* hit, float* rgb, rt_pick_event* events, size_t cap, size_t* n_events) {
+	if (!sc || !e || !s || max_depth < 0 || max_depth > 30 || (cap > 0 && !events) || cap > (1u << 24)) { rt::set_error("rt_trace_pick: bad argument"); return RT_EINVAL; }
+	if (n_events) *n_events = 0;
+	sc->drain();   // lane 0's queues are used directly below
+	HIPCHK(hipSetDevice(sc->device));
+	DevBuf de, ds, dhit, did, dt, drgb, dev, dcount;
+	if (int rc = de.alloc(12)) return rc;
+	if (int rc = ds.alloc(12)) return rc;
+	if (int rc = dhit.alloc(1)) return rc;
+	if (int rc = did.alloc(4)) return rc;
+	if (int rc = dt.alloc(4)) return rc;
+	if (int rc = drgb.alloc(12)) return rc;
+	if (int rc = dev.alloc(std::max<size_t>(cap, 1) * sizeof(rt_pick_event))) return rc;
+	if (int rc = dcount.alloc(4)) return rc;
+	HIPCHK(hipMemcpy(de.p, e, 12, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(ds.p, s, 12, hipMemcpyHostToDevice));
+	HIPCHK(hipMemset(dcount.p, 0, 4));
+	hipStream_t st = nullptr;
+	rt_scene::Lane* ln = &sc->lanes[0];
+	if (int rc = begin(sc, ln, st, 0)) return rc;
+	if (int rc = sc->ensureAccum(1)) return rc;
+	Run run{ sc, ln, st, {}, max_depth, seed, 0u, 1u };
+	run.src.a = de.as<float>(); run.src.b = ds.as<float>();
+	run.src.outHit = dhit.as<uint8_t>(); run.src.outId = did.as<int32_t>(); run.src.outT = dt.as<float>();
+	run.pick = RtPick{ dev.as<rt_pick_event>(), dcount.as<uint32_t>(), (uint32_t)cap };
+	if (int rc = run.all(1)) return rc;
+	rtk_resolve(st, sc->accum, 0, 0, 0, 1, 0, 1u, 1, 1, drgb.as<float>());
+	if (int rc = finish(sc, ln, st, run, nullptr)) return rc;
+	uint32_t count = 0;
+	HIPCHK(hipMemcpy(&count, dcount.p, 4, hipMemcpyDeviceToHost));
+	if (n_events) *n_events = count;
+	if (events && count > 0) HIPCHK(hipMemcpy(events, dev.p, std::min<size_t>(count, cap) * sizeof(rt_pick_event), hipMemcpyDeviceToHost));
+	if (hit) HIPCHK(hipMemcpy(hit, dhit.p, 1, hipMemcpyDeviceToHost));
+	if (rgb) HIPCHK(hipMemcpy(rgb, drgb.p, 12, hipMemcpyDeviceToHost));
 	return RT_OK;
 }
 

@@ -860,13 +860,24 @@ __global__ __launch_bounds__(kBlock) void k_export_hits(DevScene S, RtQueue hq, 
 	if (t) t[i] = h ? qf(hq, HQ_T, i) : 0.0f;
 }
 
+// rt_trace_pick: one event of the narration (include/rt_capi.h)
+__device__ __forceinline__ void pickEmit(const RtPick& P, uint32_t path, int kind, int arg, int flags, f3 p) {
+	const uint32_t i = atomicAdd(P.count, 1u);
+	if (i < P.cap) {
+		rt_pick_event e;
+		e.path = path; e.kind = kind; e.arg = arg; e.flags = flags; e.p[0] = p.x; e.p[1] = p.y; e.p[2] = p.z;
+		P.ev[i] = e;
+	}
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Object::transmitRay objects.cpp:107-140 (+ Plane:: :224-229, Triangle:: :273-275).
 // Where the exit search on the ray's own object fails, the reference continues from whatever an earlier ray left in
 // the object's hit cache; like the oracle restatement this uses the current point / previous normal instead.
 // ---------------------------------------------------------------------------------------------------------
-template <bool CSG, class Store>
-__device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refraction, f3 inPoint, f3 inVector, f3 inNormal, f3& outPoint, f3& outVector, Store& csgStore) {
+template <bool CSG, bool PICK, class Store>
+__device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refraction, f3 inPoint, f3 inVector, f3 inNormal, f3& outPoint, f3& outVector, Store& csgStore,
+                                   const RtPick& pick, uint32_t path) {
 	const uint32_t type = RT_PRIM_TYPE(ref), ix = RT_PRIM_INDEX(ref);
 	if (type == RT_PRIM_PLANE || refraction == 0) {
 		outVector = inVector;
@@ -907,6 +918,7 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 		outPoint = hp;
 		result = refractRay(innerVector, outNormal, refraction, outVector);
 		if (!result) {
+			if (PICK) pickEmit(pick, path, RT_PICK_INTERIOR, reflections, 0, outPoint);   // objects.cpp:129-131
 			innerVector = reflectRay(-innerVector, outNormal);
 			currentPoint = outPoint;
 			reflections++;
@@ -918,10 +930,10 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 // ---------------------------------------------------------------------------------------------------------
 // shade: everything Object::lightPoint does except the shadow rays
 // ---------------------------------------------------------------------------------------------------------
-template <bool CSG>
+template <bool CSG, bool PICK>
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
                                                   RtAccum A, uint32_t aaSq, int maxDepth, int wantSurfaces,
-                                                  uint8_t* outHit, int32_t* outId, float* outT) {
+                                                  uint8_t* outHit, int32_t* outId, float* outT, RtPick pick) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	// every record is read at once (index clamped, result masked): one memory round trip instead of two
 	const uint32_t ic = i < n ? i : 0u;
@@ -941,6 +953,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 		if (outT) outT[pixKey] = hit ? t : 0.0f;
 	}
 	if (live && !hit) accumAdd(A, pixel, w * background);   // q1.cpp:143-145 / objects.cpp:68-69,94-95
+	if (PICK && live && !hit && path > 1u) pickEmit(pick, path, RT_PICK_MISS, 0, 0, mk3(0, 0, 0));
 
 	bool wantR = false, wantX = false, wantS = false;
 	float refraction = 0;
@@ -981,6 +994,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 
 		const bool transmissive = !isZero3(m.transmissive);
 		const f3 kt = ld3(m.transmissive);
+		if (PICK) pickEmit(pick, path, RT_PICK_HIT, (int)type, (isZero3(m.reflective) ? 0 : 1) | (transmissive ? 2 : 0), p);   // raytracer.cpp:323-324
 		wl = transmissive ? w * (mk3(1.0f, 1.0f, 1.0f) - kt) : w;   // objects.cpp:103
 		const int depth = 31 - __clz((int)path);   // reflectionCount of this ray
 
@@ -995,8 +1009,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 			rO = p + 1e-5f * R;
 			rD = (p + R) - rO;
 			rW = wl * ld3(m.reflective);
-			if (depth + 1 > maxDepth) accumAdd(A, pixel, rW * background);   // raytracer.cpp:308-313 -> objects.cpp:68-69
-			else wantR = true;
+			if (depth + 1 > maxDepth) {   // raytracer.cpp:308-313 -> objects.cpp:68-69
+				accumAdd(A, pixel, rW * background);
+				if (PICK) pickEmit(pick, path * 2u, RT_PICK_MAXDEPTH, 0, 0, mk3(0, 0, 0));
+			} else wantR = true;
 		}
 		// objects.cpp:81-104: the search for the exit point (Object::transmitRay: up to 16 internal reflections, each a full
 		// hit test of the object) is not done here: a few such rays would hold their whole wave.  They are queued, and
@@ -1071,8 +1087,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 // workgroups are single waves and, for CSG objects, the interval lists live in LDS (LDSCSG) whenever the scene's
 // largest program fits (CsgLds; rtk_transmit decides).
 constexpr int kTransmitBlock = 64;
-template <bool CSG, bool LDSCSG>
-__global__ __launch_bounds__(kTransmitBlock) void k_transmit(DevScene S, RtQueue tq, RtQueue nq, RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth) {
+template <bool CSG, bool LDSCSG, bool PICK>
+__global__ __launch_bounds__(kTransmitBlock) void k_transmit(DevScene S, RtQueue tq, RtQueue nq, RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth, RtPick pick) {
 	extern __shared__ __align__(16) uint8_t transmitLds[];
 	const uint32_t i = blockIdx.x * kTransmitBlock + threadIdx.x;
 	const uint32_t n = ctr->trans_count < tq.cap ? ctr->trans_count : tq.cap;
@@ -1091,17 +1107,20 @@ __global__ __launch_bounds__(kTransmitBlock) void k_transmit(DevScene S, RtQueue
 		bool ok;
 		if constexpr (CSG && LDSCSG) {
 			CsgLds store = csgLdsStore(transmitLds, kTransmitBlock, (int)threadIdx.x, S.csg_cap);
-			ok = transmitRay<CSG>(S, prim, qf(tq, TQ_REFR, i), p, d, N, outPoint, outVector, store);
+			ok = transmitRay<CSG, PICK>(S, prim, qf(tq, TQ_REFR, i), p, d, N, outPoint, outVector, store, pick, path);
 		} else {
 			CsgScratch store;
-			ok = transmitRay<CSG>(S, prim, qf(tq, TQ_REFR, i), p, d, N, outPoint, outVector, store);
+			ok = transmitRay<CSG, PICK>(S, prim, qf(tq, TQ_REFR, i), p, d, N, outPoint, outVector, store, pick, path);
 		}
+		if (PICK) pickEmit(pick, path, ok ? RT_PICK_EXIT : RT_PICK_LOST, 0, 0, ok ? outPoint : mk3(0, 0, 0));   // objects.cpp:90-92, 100-101
 		if (ok) {
 			tO = outPoint;
 			tD = (outPoint + outVector) - outPoint;
 			const int depth = 31 - __clz((int)path);
-			if (depth + 1 > maxDepth) accumAdd(A, pixKey / aaSq, tW * ld3(S.background));   // raytracer.cpp:308-313 -> objects.cpp:94-95
-			else want = true;
+			if (depth + 1 > maxDepth) {   // raytracer.cpp:308-313 -> objects.cpp:94-95
+				accumAdd(A, pixKey / aaSq, tW * ld3(S.background));
+				if (PICK) pickEmit(pick, path * 2u + 1u, RT_PICK_MAXDEPTH, 0, 0, mk3(0, 0, 0));
+			} else want = true;
 		}
 	}
 	const uint32_t st = wavePush(want, &ctr->next_count);
@@ -1424,18 +1443,28 @@ void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, 
 	RT_LAUNCH(k_export_hits, n, st, S, hq, n, hit, id, t);
 }
 void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
-               uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT) {
-	if (csg) RT_LAUNCH((k_shade<true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT);
-	else RT_LAUNCH((k_shade<false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT);
+               uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick) {
+	if (pick.ev) {   // rt_trace_pick: the variants that narrate
+		if (csg) RT_LAUNCH((k_shade<true, true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick);
+		else RT_LAUNCH((k_shade<false, true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick);
+		return;
+	}
+	if (csg) RT_LAUNCH((k_shade<true, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick);
+	else RT_LAUNCH((k_shade<false, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick);
 }
-void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint32_t maxRequests, RtQueue nq, RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth) {
+void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint32_t maxRequests, RtQueue nq, RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth, RtPick pick) {
 	if (maxRequests == 0) return;
 	const dim3 grid((maxRequests + kTransmitBlock - 1) / kTransmitBlock), block(kTransmitBlock);
 	const size_t lds = RTD_CSG_LDS_BYTES(kTransmitBlock, S.csg_cap, S.csg_nodes_max);
 	static const bool noLds = getenv("RT_NO_CSG_LDS") != nullptr;
-	if (!csg) hipLaunchKernelGGL((k_transmit<false, false>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth);
-	else if (lds <= 64u * 1024u && !noLds) hipLaunchKernelGGL((k_transmit<true, true>), grid, block, lds, st, S, tq, nq, ctr, A, aaSq, maxDepth);
-	else hipLaunchKernelGGL((k_transmit<true, false>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth);
+	if (pick.ev) {   // rt_trace_pick: one ray tree, no need for the LDS lists
+		if (csg) hipLaunchKernelGGL((k_transmit<true, false, true>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
+		else hipLaunchKernelGGL((k_transmit<false, false, true>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
+		return;
+	}
+	if (!csg) hipLaunchKernelGGL((k_transmit<false, false, false>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
+	else if (lds <= 64u * 1024u && !noLds) hipLaunchKernelGGL((k_transmit<true, true, false>), grid, block, lds, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
+	else hipLaunchKernelGGL((k_transmit<true, false, false>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
 }
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                       RtAccum A, uint32_t aaSq, RtCounters* ctr) {

@@ -166,3 +166,71 @@ def test_odd_frame_shapes(W, H, aa, gpu_scenes, flat_scenes):
     for rank in range(5):                                  # more ranks than tiles for the small frames
         sc.render_into(full.data_ptr(), W, H, aa=aa, camera=cam, tile_rank=rank, tile_ranks=5)
     assert np.array_equal(bits(full.cpu().numpy()), bits(img))
+
+
+@pytest.mark.parametrize("name", ["a", "b", "e", "g", "h", "k"])
+def test_pick_narration_vs_reference(name, gpu_scenes, flat_scenes):
+    """trace(e, s, colour, pick=true): what the compiled reference prints on std::cout for 64 pixels of a 160x120 frame
+    (tests/golden/pick_<scene>.txt, tools/make_pick_golden.py) -- hits, reflections, interior reflections of the exit search,
+    lost rays, the depth limit -- against rt_trace_pick + rt_pick_narration."""
+    import os
+    import raytracer_amd as rt
+    fs = flat_scenes(name)
+    sc = gpu_scenes(name)
+    W, H = 160, 120
+    cam = rt.Camera(fs.fov, W, H)
+    s = oracle.primary_targets(cam, W, H).reshape(H, W, 3)
+    blocks = open(os.path.join(os.path.dirname(__file__), "golden", f"pick_{name}.txt")).read().split("== pixel ")[1:]
+    assert len(blocks) == 64
+    for b in blocks:
+        head, _, rest = b.partition("\n")
+        x, y = map(int, head.split())
+        want, _, verdict = rest.rpartition("== ")
+        hit, rgb, text = sc.trace_pick((0, 0, 0), s[y, x])
+        assert hit == (verdict.strip() == "hit"), (x, y)
+        assert text == want, f"pixel {x} {y}:\n{text}\n-- reference --\n{want}"
+
+
+def test_reference_api_client_end_to_end(tmp_path):
+    """A C++ caller written like q1.cpp (tests/shim_client.cpp: choose_scene, fov, background_colour, trace with and without
+    pick, shadowRay) built against include/raytracer.h: its output equals what the C-ABI gives for the same rays."""
+    import os
+    import subprocess
+    import raytracer_amd as rt
+    from raytracer_amd import scenes
+    from test_host_capi import build_shim_client
+    exe = build_shim_client(tmp_path)
+    os.makedirs(tmp_path / "scenes")
+    path = scenes.random_scene(str(tmp_path / "scenes"), seed=19)
+    name = os.path.basename(path)[:-5]
+    W, H = 160, 120
+    pixels = [(x, y) for y in range(10, H, 25) for x in range(12, W, 31)]
+    out = subprocess.run([exe, name, str(W), str(H)] + [str(v) for p in pixels for v in p], cwd=str(tmp_path), check=True, capture_output=True, text=True).stdout
+    flat = rt.FlatScene.from_json(path)
+    sc = rt.Scene(flat, 0)
+    cam = rt.Camera(flat.fov, W, H)
+    s = oracle.primary_targets(cam, W, H).reshape(H, W, 3)
+    assert f"Loading scene {name}" in out
+    head = out[:out.index("== pixel")].splitlines()[-1].split()
+    assert float(head[1]) == flat.fov and np.allclose([float(v) for v in head[3:6]], flat.background)
+    blocks = out.split("== pixel ")[1:]
+    assert len(blocks) == len(pixels)
+    for (x, y), b in zip(pixels, blocks):
+        lines = b.splitlines()
+        assert lines[0].split() == [str(x), str(y)]
+        k = next(i for i, l in enumerate(lines) if l.startswith("== "))
+        narration = "".join(l + "\n" for l in lines[1:k])
+        hit, rgb, text = sc.trace_pick((0, 0, 0), s[y, x])
+        assert narration == text and (lines[k] == "== hit") == hit
+        col = lines[k + 1].split()
+        assert col[-1] == "1"                                     # pick and non-pick calls agree
+        if hit:
+            assert np.array_equal(np.array(col[1:4], np.float32), rgb)
+            sh = lines[k + 2].split()
+            r = sc.shadow_batch(s[y, x][None], np.array([[0.5, 6.0, -1.0]], np.float32))
+            assert int(sh[1]) == int(r["lit"][0]) and np.array_equal(np.array(sh[2:5], np.float32), r["shadow"][0])
+        else:
+            assert col[1:4] == ["-1", "-1", "-1"]                 # colour untouched on a miss (raytracer.cpp:320-321)
+    tail = lines[-2:] if lines[-1].startswith("beyond") else out.splitlines()[-2:]
+    assert tail[0] == "Maximum number of reflections reached." and tail[1].split()[-4:] == ["0", "0", "0", "0"]
+    sc.close()

@@ -195,3 +195,26 @@ def test_binary_mesh_file_loads_to_the_same_scene_as_json(tmp_path):
     (tmp_path / "short.json").write_text(json.dumps(dict(base, objects=[{"type": "mesh", "material": {}, "file": "short.bin"}])))
     with pytest.raises(rt.capi.RtError):
         rt.FlatScene.from_json(str(tmp_path / "short.json"))
+
+
+def build_shim_client(tmp_path):
+    """tests/shim_client.cpp (a q1.cpp-style caller of the reference API) against include/raytracer.h + libraytracer_amd.so."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "shim_client")
+    lib_dir = os.path.join(ROOT, "raytracer_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "shim_client.cpp"), "-o", exe,
+                    "-L" + lib_dir, "-lraytracer_amd", "-Wl,-rpath," + lib_dir], check=True, capture_output=True)
+    return exe
+
+
+def test_reference_api_header_compiles_and_links(tmp_path):
+    """The drop-in boundary: a caller of choose_scene / trace / shadowRay / fov / background_colour builds against this
+    repository's raytracer.h and resolves every rtapi_* symbol in the library (it is not run here: no GPU)."""
+    build_shim_client(tmp_path)
+    lib = capi.load()
+    header = open(os.path.join(ROOT, "include", "raytracer.h")).read()
+    for name in set(re.findall(r"\b(rtapi_[a-z0-9_]+)\s*\(", header)):
+        assert hasattr(lib, name), f"{name} is declared in raytracer.h but not exported"

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""tests/golden/pick_<scene>.txt: the compiled reference's own narration of trace(..., pick = true) for a grid of pixels
+(oracle/_ref/ref_driver ... pick, built by `make -C oracle ref`; runs only in the build container, where /root/reference is)."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+REF_SRC = "/root/reference/src"
+W, H = 160, 120
+PIXELS = [(x, y) for y in range(7, H, 15) for x in range(9, W, 19)]
+
+
+def main():
+    for scene in sys.argv[1:] or ["a", "b", "e", "g", "h", "k"]:
+        args = [DRIVER, scene, str(W), str(H), "pick"] + [str(v) for p in PIXELS for v in p]
+        out = subprocess.run(args, cwd=REF_SRC, check=True, capture_output=True, text=True).stdout
+        out = out[out.index("== pixel"):]
+        with open(os.path.join(ROOT, "tests", "golden", f"pick_{scene}.txt"), "w") as f:
+            f.write(out)
+        print(scene, len(PIXELS), "pixels,", out.count("\n"), "lines,", out.count("interior reflection"), "interior reflections,",
+              out.count("Maximum number"), "depth limits,", out.count("ray lost"), "lost rays")
+
+
+if __name__ == "__main__":
+    main()

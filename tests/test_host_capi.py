@@ -218,3 +218,13 @@ def test_reference_api_header_compiles_and_links(tmp_path):
     header = open(os.path.join(ROOT, "include", "raytracer.h")).read()
     for name in set(re.findall(r"\b(rtapi_[a-z0-9_]+)\s*\(", header)):
         assert hasattr(lib, name), f"{name} is declared in raytracer.h but not exported"
+
+
+def test_reference_api_missing_scene_exits_like_the_reference(tmp_path):
+    """choose_scene on a scene file that does not exist: the reference prints "Unable to open scene file ..." and calls
+    exit(EXIT_FAILURE) (raytracer.cpp:127-130); so does the stand-in, before anything touches a GPU."""
+    import subprocess
+    exe = build_shim_client(tmp_path)
+    r = subprocess.run([exe, "no_such_scene", "16", "16"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 1
+    assert "Loading scene no_such_scene" in r.stdout and "Unable to open scene file scenes/no_such_scene.json" in r.stdout

@@ -234,3 +234,29 @@ def test_reference_api_client_end_to_end(tmp_path):
     tail = lines[-2:] if lines[-1].startswith("beyond") else out.splitlines()[-2:]
     assert tail[0] == "Maximum number of reflections reached." and tail[1].split()[-4:] == ["0", "0", "0", "0"]
     sc.close()
+
+
+def test_headless_renderer_cli(tmp_path, scene_dir, gpu_scenes, flat_scenes):
+    """raytracer_amd/bin/rt_render (the headless stand-in for the GLUT front end): scene file in, BMP out -- the same
+    pixels as the library's frame, quantised by q -> uint8(q * 255 + 0.5)."""
+    import json
+    import os
+    import subprocess
+    import raytracer_amd as rt
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "raytracer_amd", "bin", "rt_render")
+    if not os.path.exists(exe):
+        pytest.skip("rt_render is not built (make cli)")
+    out = str(tmp_path / "c.bmp")
+    r = subprocess.run([exe, str(scene_dir / "c.rtscene"), "-o", out, "-w", "200", "-h", "100", "-aa", "2"], check=True, capture_output=True, text=True)
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    fs, sc = flat_scenes("c"), gpu_scenes("c")
+    img = sc.render(200, 100, aa=2, camera=rt.Camera(fs.fov, 200, 100))
+    assert info["rays_nearest"] == sc.last_stats["rays_nearest"] and info["rays_shadow"] == sc.last_stats["rays_shadow"]
+    data = open(out, "rb").read()
+    assert data[:2] == b"BM" and int.from_bytes(data[18:22], "little") == 200 and int.from_bytes(data[22:26], "little") == 100
+    off = int.from_bytes(data[10:14], "little")
+    row = (200 * 3 + 3) // 4 * 4
+    px = np.frombuffer(data, np.uint8, count=row * 100, offset=off).reshape(100, row)[:, :600].reshape(100, 200, 3)[:, :, ::-1]
+    # BMP rows are stored bottom-up and the frame's row 0 is the bottom row (glDrawPixels order): same order
+    assert np.array_equal(px, rgb8(img))

@@ -197,7 +197,7 @@ def test_binary_mesh_file_loads_to_the_same_scene_as_json(tmp_path):
         rt.FlatScene.from_json(str(tmp_path / "short.json"))
 
 
-def build_shim_client(tmp_path):
+def build_shim_client(tmp_path, extra=()):
     """tests/shim_client.cpp (a q1.cpp-style caller of the reference API) against include/raytracer.h + libraytracer_amd.so."""
     import shutil
     import subprocess
@@ -205,9 +205,17 @@ def build_shim_client(tmp_path):
         pytest.skip("no g++")
     exe = str(tmp_path / "shim_client")
     lib_dir = os.path.join(ROOT, "raytracer_amd", "lib")
-    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "shim_client.cpp"), "-o", exe,
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", *extra, "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "shim_client.cpp"), "-o", exe,
                     "-L" + lib_dir, "-lraytracer_amd", "-Wl,-rpath," + lib_dir], check=True, capture_output=True)
     return exe
+
+
+def test_reference_api_header_with_the_reference_glm_types(tmp_path):
+    """With RT_USE_GLM, point3 / colour3 are glm::vec3 as in the reference (raytracer.h:9-10): the same caller builds against
+    the reference's vendored GLM (only where the reference tree is present: the build container)."""
+    if not os.path.isdir("/root/reference/glm"):
+        pytest.skip("the reference tree is not here")
+    build_shim_client(tmp_path, extra=("-DRT_USE_GLM", "-I/root/reference/glm", "-w"))
 
 
 def test_reference_api_header_compiles_and_links(tmp_path):

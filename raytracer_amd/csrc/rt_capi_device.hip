@@ -214,12 +214,15 @@ void subBox(const rt_flat_scene* s, const AugTree& A, uint32_t first, uint32_t c
 		box[2 * a] = lo[a] - pad; box[2 * a + 1] = hi[a] + pad;
 	}
 }
-// median split on the longest axis of the centroid bounds; returns a child reference
-int32_t buildSub(const rt_flat_scene* s, AugTree& A, uint32_t first, uint32_t count, int depth, int& maxDepth) {
-	maxDepth = std::max(maxDepth, depth);
+// The sub-tree over subTris[first, first+count) of one fat leaf, built into vectors of its own (nodes and leaves numbered
+// from 0) so that the fat leaves of a scene -- 65 536 of them under C5's depth-capped tree -- can be built on all host cores;
+// each touches only its own range of subTris / subKeys.  Median split on the longest axis of the centroid bounds.
+struct SubTree { std::vector<AugTree::Node> nodes; std::vector<AugTree::Leaf> leaves; int maxDepth = 0; int32_t root = 0; };
+int32_t buildSub(const rt_flat_scene* s, AugTree& A, SubTree& T, uint32_t first, uint32_t count, int depth) {
+	T.maxDepth = std::max(T.maxDepth, depth);
 	if (count <= RT_TREELET_SUBLEAF_MAX) {
-		A.leaves.push_back({ 0, true, first, count });
-		return ~(int32_t)(A.leaves.size() - 1);
+		T.leaves.push_back({ 0, true, first, count });
+		return ~(int32_t)(T.leaves.size() - 1);
 	}
 	float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
 	auto centroid = [&](uint32_t tri, int a) { const rt_tri& t = s->tris[tri]; return (t.p0[a] + t.p1[a] + t.p2[a]) * (1.0f / 3.0f); };
@@ -237,15 +240,15 @@ int32_t buildSub(const rt_flat_scene* s, AugTree& A, uint32_t first, uint32_t co
 		return cx < cy || (cx == cy && x.second < y.second);
 	});
 	for (uint32_t i = 0; i < count; i++) { A.subTris[first + i] = tmp[i].first; A.subKeys[first + i] = tmp[i].second; }
-	const int32_t me = (int32_t)A.nodes.size();
-	A.nodes.push_back({});
+	const int32_t me = (int32_t)T.nodes.size();
+	T.nodes.push_back({});
 	AugTree::Node n{};
 	n.cons = true;
 	subBox(s, A, first, half, n.box[0]);
 	subBox(s, A, first + half, count - half, n.box[1]);
-	n.child[0] = buildSub(s, A, first, half, depth + 1, maxDepth);
-	n.child[1] = buildSub(s, A, first + half, count - half, depth + 1, maxDepth);
-	A.nodes[me] = n;
+	n.child[0] = buildSub(s, A, T, first, half, depth + 1);
+	n.child[1] = buildSub(s, A, T, first + half, count - half, depth + 1);
+	T.nodes[(size_t)me] = n;
 	return me;
 }
 
@@ -257,6 +260,33 @@ void buildAugTree(const rt_flat_scene* s, bool split, AugTree& A) {
 	// depths of the reference nodes (children follow their parents in the pre-order array)
 	std::vector<int> depthOf((size_t)s->n_bvh_nodes, 0);
 	depthOf[(size_t)s->root_child] = 1;
+	// pass 1: the fat leaves and their triangles
+	struct Job { uint32_t first, count; int depth; SubTree tree; };
+	std::vector<Job> jobs;
+	for (int32_t i = 0; i < s->n_bvh_nodes; i++) {
+		const rt_bvh_node& b = s->bvh_nodes[i];
+		for (int k = 0; k < 2; k++) {
+			const int32_t c = b.child[k];
+			if (c >= 0) { depthOf[(size_t)c] = depthOf[(size_t)i] + 1; continue; }
+			const TriRun r = leafRun(s, c);
+			if (split && r.count > RT_TREELET_EMBED_MAX) {
+				jobs.push_back({ (uint32_t)A.subTris.size(), r.count, depthOf[(size_t)i] + 1, {} });
+				for (uint32_t j = 0; j < r.count; j++) { A.subTris.push_back(r.first + j); A.subKeys.push_back((uint32_t)~c + j + 1u); }
+			}
+		}
+	}
+	// pass 2: their sub-trees, independent of each other
+	{
+		const unsigned nThreads = jobs.size() < 64 ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+		std::vector<std::thread> pool;
+		for (unsigned t = 0; t < nThreads; t++)
+			pool.emplace_back([&, t] {
+				for (size_t j = t; j < jobs.size(); j += nThreads) jobs[j].tree.root = buildSub(s, A, jobs[j].tree, jobs[j].first, jobs[j].count, jobs[j].depth);
+			});
+		for (auto& th : pool) th.join();
+	}
+	// pass 3: the reference nodes, with the sub-trees spliced in where their leaves were (same numbering as a sequential build)
+	size_t next = 0;
 	for (int32_t i = 0; i < s->n_bvh_nodes; i++) {
 		const rt_bvh_node& b = s->bvh_nodes[i];
 		AugTree::Node n{};
@@ -264,14 +294,16 @@ void buildAugTree(const rt_flat_scene* s, bool split, AugTree& A) {
 		n.cons = false;
 		for (int k = 0; k < 2; k++) {
 			const int32_t c = b.child[k];
-			if (c >= 0) { n.child[k] = c; depthOf[(size_t)c] = depthOf[(size_t)i] + 1; continue; }
+			if (c >= 0) { n.child[k] = c; continue; }
 			const TriRun r = leafRun(s, c);
 			if (split && r.count > RT_TREELET_EMBED_MAX) {
-				const uint32_t first = (uint32_t)A.subTris.size();
-				for (uint32_t j = 0; j < r.count; j++) { A.subTris.push_back(r.first + j); A.subKeys.push_back((uint32_t)~c + j + 1u); }
-				int maxDepth = 0;
-				n.child[k] = buildSub(s, A, first, r.count, depthOf[(size_t)i] + 1, maxDepth);
-				A.depth = std::max(A.depth, maxDepth);
+				const SubTree& T = jobs[next++].tree;
+				const int32_t nodeBase = (int32_t)A.nodes.size(), leafBase = (int32_t)A.leaves.size();
+				auto global = [&](int32_t ref) { return ref >= 0 ? nodeBase + ref : ~(leafBase + ~ref); };
+				for (AugTree::Node m : T.nodes) { m.child[0] = global(m.child[0]); m.child[1] = global(m.child[1]); A.nodes.push_back(m); }
+				A.leaves.insert(A.leaves.end(), T.leaves.begin(), T.leaves.end());
+				n.child[k] = global(T.root);
+				A.depth = std::max(A.depth, T.maxDepth);
 			} else {
 				A.leaves.push_back({ c, false, r.first, r.count });
 				n.child[k] = ~(int32_t)(A.leaves.size() - 1);
@@ -720,6 +752,9 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	if ((rc = sc->upload(s->textures, s->n_textures, &D.textures))) return fail(rc);
 	if ((rc = sc->upload(s->texels, s->n_texel_bytes, &D.texels))) return fail(rc);
 	if ((rc = sc->upload(s->leaf_prims, s->n_leaf_prims, &D.leaf_prims))) return fail(rc);
+	const bool timing = getenv("RT_LOAD_TIMING") != nullptr;
+	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double tUp0 = now();
 	{
 		MeshTrees mt;
 		buildMeshTrees(s, mt);
@@ -732,12 +767,15 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 		std::vector<rt_bvh_node> treelets;
 		bool externalRuns = false;
 		AugTree aug;
+		const double tA0 = now();
 		buildAugTree(s, getenv("RT_NO_SPLIT") == nullptr, aug);
+		const double tA1 = now();
 		if (aug.depth > RT_PACKET_STACK_DEPTH) buildAugTree(s, false, aug);   // (a leaf of > 4 * 2^20 triangles)
 		int levels = buildTreelets(s, aug, getenv("RT_NO_EMBED") == nullptr, treelets, externalRuns);
 		if (levels > RT_TREELET_MAX_LEVELS) { buildAugTree(s, false, aug); levels = buildTreelets(s, aug, false, treelets, externalRuns); }
 		if (levels < 0) return fail(RT_EINVAL);
 		if (levels > RT_TREELET_MAX_LEVELS || treelets.size() / RT_TREELET_SLOTS >= RT_TREELET_CONS / RT_TREELET_SLOTS) { rt::set_error("BVH too deep or too large for the treelet layout"); return fail(RT_ELIMIT); }
+		if (timing) fprintf(stderr, "[upload] arrays + mesh trees %.2f s, sub-trees %.2f s, treelets %.2f s\n", tA0 - tUp0, tA1 - tA0, now() - tA1);
 		D.treelet_levels = levels;
 		D.treelet_staging = externalRuns ? 1 : 0;
 		const rt_bvh_node* tl = nullptr;

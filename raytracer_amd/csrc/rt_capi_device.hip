@@ -394,6 +394,8 @@ int buildTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std::vec
 	int levels = 0;
 	struct Member { int32_t node; bool embedLeaf[2]; };
 	std::vector<Member> member;
+	std::vector<int32_t> childSlot;   // per member, per child: slot of an in-treelet inner child, -1 otherwise
+	out.reserve((A.nodes.size() / 2 + 64) * RT_TREELET_SLOTS);   // (about what a tree of 4-triangle sub-leaves needs: no regrowth copies of a 0.6 GB array)
 	// triangles a leaf brings into the treelet if it is embedded: sub-leaves always, reference runs up to RT_TREELET_EMBED_MAX
 	auto embeddable = [&](int32_t c) -> uint32_t {
 		const AugTree::Leaf& L = A.leaves[(size_t)~c];
@@ -421,7 +423,7 @@ int buildTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std::vec
 			return true;
 		};
 		join(roots[t].node, true);
-		std::vector<int32_t> childSlot;   // per member, per child: slot of an in-treelet inner child, -1 otherwise
+		childSlot.clear();
 		for (size_t i = 0; i < member.size(); i++) {
 			const AugTree::Node& b = A.nodes[(size_t)member[i].node];
 			for (int k = 0; k < 2; k++) {

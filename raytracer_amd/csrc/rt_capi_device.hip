@@ -61,6 +61,7 @@ struct rt_scene {
 	uint32_t qcap = 0;
 	int maxBlocks = 2048;            // grid cap of the persistent kernels
 	int maxBlocksPacketNear = 2048;  // ... of the nearest-hit packet kernel (see rt_scene_upload)
+	int maxBlocksPacketShadow = 2048;   // ... and of the shadow packet kernel
 	std::vector<Lane> lanes;
 	RtAccum accum{};
 	// Frames are rendered asynchronously: rt_render_submit queues one shard of the frame on every lane (shard k = the
@@ -527,7 +528,7 @@ struct Run {
 			const uint32_t nsurf = ln->ctrHost->surf_count;
 			if (nsurf > 0 && sc->shadowRaysPerSurface > 0) {
 				if (timeK) HIPCHK(hipEventRecord(ln->ev[4], st));
-				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, coherent(level), sc->maxBlocks, ln->surfq, nsurf, sc->pointLights, sc->nPointLights, sc->accum, aaSq, ln->ctr);
+				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, coherent(level), coherent(level) ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nsurf, sc->pointLights, sc->nPointLights, sc->accum, aaSq, ln->ctr);
 				for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, count, ln->surfq, nsurf, al.first, al.second, seed, sc->accum, aaSq, ln->ctr);
 				if (timeK) { HIPCHK(hipEventRecord(ln->ev[5], st)); shadowPending = true; }
 				shadowRays += (uint64_t)nsurf * sc->shadowRaysPerSurface;
@@ -737,6 +738,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	sc->device = device;
 	sc->maxBlocks = std::max(1, prop.multiProcessorCount) * (int)std::max<uint32_t>(1, envU32("RT_BLOCKS_PER_CU", 8));
 	sc->maxBlocksPacketNear = std::max(1, prop.multiProcessorCount) * (int)std::max<uint32_t>(1, envU32("RT_BLOCKS_PER_CU_NEAR", 2));
+	sc->maxBlocksPacketShadow = std::max(1, prop.multiProcessorCount) * (int)std::max<uint32_t>(1, envU32("RT_BLOCKS_PER_CU_SHADOW", 3));
 	auto fail = [&](int rc) { rt_scene_free(sc); return rc; };
 	DevScene& D = sc->dev;
 	int rc;

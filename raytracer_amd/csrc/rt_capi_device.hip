@@ -61,7 +61,8 @@ struct rt_scene {
 	uint32_t qcap = 0;
 	int maxBlocks = 2048;            // grid cap of the persistent kernels
 	int maxBlocksPacketNear = 2048;  // ... of the nearest-hit packet kernel (see rt_scene_upload)
-	int maxBlocksPacketShadow = 2048;   // ... and of the shadow packet kernel
+	int maxBlocksPacketShadow = 2048;   // ... and of the shadow packet kernels (one light per packet / two)
+	int maxBlocksPacketShadow2 = 2048;
 	std::vector<Lane> lanes;
 	RtAccum accum{};
 	// Frames are rendered asynchronously: rt_render_submit queues one shard of the frame on every lane (shard k = the
@@ -515,6 +516,17 @@ struct Run {
 			rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, n, ln->ray[cur ^ 1], ln->surfq, ln->transq, ln->ctr, sc->accum, aaSq, maxDepth,
 			          sc->shadowRaysPerSurface > 0, level == 0 ? src.outHit : nullptr, src.outId, src.outT, pick);
 			if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, n, ln->ray[cur ^ 1], ln->ctr, sc->accum, aaSq, maxDepth, pick);
+			// Level 0 of a frame lit by point-type lights only: the shadow packets are queued before the host has seen the
+			// counts (the kernels read them on the device), and the host waits for the count read-back while they run --
+			// the lane's stream never idles through a host round trip.
+			const bool early = coherent(level) && !timeK && !count && sc->areaLights.empty() && sc->nPointLights > 0 && sc->shadowRaysPerSurface > 0;
+			if (early) {
+				HIPCHK(hipGetLastError());
+				HIPCHK(hipMemcpyAsync(ln->ctrHost, ln->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost, st));
+				HIPCHK(hipEventRecord(ln->ev[4], st));
+				rtk_shadow_point(st, sc->dev, sc->hasCsg, false, true, sc->maxBlocksPacketShadow, ln->surfq, n, sc->pointLights, sc->nPointLights, sc->accum, aaSq, ln->ctr, true, sc->maxBlocksPacketShadow2);
+				HIPCHK(hipEventSynchronize(ln->ev[4]));
+			} else
 			if (int rc = syncCounters()) return rc;
 			if (timeK) {
 				float ms = 0;
@@ -526,9 +538,10 @@ struct Run {
 			// inactive slots of a partial edge tile are not rays
 			nearRays += n;
 			const uint32_t nsurf = ln->ctrHost->surf_count;
-			if (nsurf > 0 && sc->shadowRaysPerSurface > 0) {
+			if (early) shadowRays += (uint64_t)nsurf * sc->shadowRaysPerSurface;
+			else if (nsurf > 0 && sc->shadowRaysPerSurface > 0) {
 				if (timeK) HIPCHK(hipEventRecord(ln->ev[4], st));
-				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, coherent(level), coherent(level) ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nsurf, sc->pointLights, sc->nPointLights, sc->accum, aaSq, ln->ctr);
+				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, coherent(level), coherent(level) ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nsurf, sc->pointLights, sc->nPointLights, sc->accum, aaSq, ln->ctr, false, sc->maxBlocksPacketShadow2);
 				for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, count, ln->surfq, nsurf, al.first, al.second, seed, sc->accum, aaSq, ln->ctr);
 				if (timeK) { HIPCHK(hipEventRecord(ln->ev[5], st)); shadowPending = true; }
 				shadowRays += (uint64_t)nsurf * sc->shadowRaysPerSurface;
@@ -739,6 +752,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	sc->maxBlocks = std::max(1, prop.multiProcessorCount) * (int)std::max<uint32_t>(1, envU32("RT_BLOCKS_PER_CU", 8));
 	sc->maxBlocksPacketNear = std::max(1, prop.multiProcessorCount) * (int)std::max<uint32_t>(1, envU32("RT_BLOCKS_PER_CU_NEAR", 2));
 	sc->maxBlocksPacketShadow = std::max(1, prop.multiProcessorCount) * (int)std::max<uint32_t>(1, envU32("RT_BLOCKS_PER_CU_SHADOW", 3));
+	sc->maxBlocksPacketShadow2 = std::max(1, prop.multiProcessorCount) * (int)std::max<uint32_t>(1, envU32("RT_BLOCKS_PER_CU_SHADOW2", 2));
 	auto fail = [&](int rc) { rt_scene_free(sc); return rc; };
 	DevScene& D = sc->dev;
 	int rc;

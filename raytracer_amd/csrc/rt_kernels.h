@@ -19,6 +19,9 @@
 #ifndef RT_SHADOW_WAVES_PER_SIMD
 #define RT_SHADOW_WAVES_PER_SIMD 4   /* k_shadow_point_packet: 128 VGPRs (at 96 its triangle early-out spills inside the walk and costs more than it saves) */
 #endif
+#ifndef RT_SHADOW2_WAVES_PER_SIMD
+#define RT_SHADOW2_WAVES_PER_SIMD 3   /* k_shadow_point_packet2 (two rays per lane): 168 VGPRs; it is launched on 3 workgroups per CU anyway */
+#endif
 #ifndef RT_AREA_WAVES_PER_SIMD
 #define RT_AREA_WAVES_PER_SIMD 4   /* register budget of k_shadow_area: 128 VGPRs (3: 10 % slower on C4, 5: spills, 60 % slower) */
 #endif
@@ -51,7 +54,7 @@
 #define RT_TREELET_SUBLEAF_MAX 4u         /* triangles per leaf of such a sub-tree */
 #define RT_TREELET_CONS (1u << 29)        /* flag on a child reference: the node belongs to a sub-tree, its box tests are conservative */
 #define RT_PACKET_STACK_DEPTH RT_STACK_DEPTH   /* wave stack entries */
-#define RT_PACKET_STACK_BYTES (RT_PACKET_STACK_DEPTH * 16)
+#define RT_PACKET_STACK_BYTES (RT_PACKET_STACK_DEPTH * 32)   /* 32 B per entry: the two-ray shadow walk carries two lane masks */
 // LDS of a packet kernel's workgroup: the root treelet once (every packet starts there; fetched when the workgroup
 // starts), then per wave one 1 KB buffer per deeper treelet level, one more when the scene has external runs to stage,
 // and the stack
@@ -105,7 +108,7 @@ void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint3
 void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
                uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick = RtPick{ nullptr, nullptr, 0 });
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
-                      RtAccum A, uint32_t aaSq, RtCounters* ctr);
+                      RtAccum A, uint32_t aaSq, RtCounters* ctr, bool countOnDevice = false, int maxBlocksPairs = 0);
 void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t samples, uint32_t seed,
                      RtAccum A, uint32_t aaSq, RtCounters* ctr);
 void rtk_shadow_query(hipStream_t st, const DevScene& S, bool csg, const float* point, const float* lightPos, uint32_t n, uint8_t* lit, float* shadow);

@@ -70,6 +70,24 @@ __device__ __forceinline__ void accumAdd(const RtAccum& A, uint32_t pixel, f3 c)
 	accumChannel(A.rgb + 2 * (size_t)A.npix, pixel, c.z);
 }
 
+// two contributions to one pixel: converted to fixed point one by one, as two accumAdd calls would, added as integers
+__device__ __forceinline__ void accumAdd2(const RtAccum& A, uint32_t pixel, f3 c1, bool has1, f3 c2, bool has2) {
+	const bool ok1 = has1 && isfinite(c1.x) && isfinite(c1.y) && isfinite(c1.z), ok2 = has2 && isfinite(c2.x) && isfinite(c2.y) && isfinite(c2.z);
+	if ((has1 && !ok1) || (has2 && !ok2)) A.nonfinite[pixel] = 1;
+	auto fixed = [](float c) -> long long {
+		if (c == 0.0f) return 0;
+		double v = (double)c * 4294967296.0;
+		if (v > 4.0e18) v = 4.0e18;
+		if (v < -4.0e18) v = -4.0e18;
+		return __double2ll_rn(v);
+	};
+	const float v1[3] = { c1.x, c1.y, c1.z }, v2[3] = { c2.x, c2.y, c2.z };
+	for (int k = 0; k < 3; k++) {
+		const long long sum = (ok1 ? fixed(v1[k]) : 0) + (ok2 ? fixed(v2[k]) : 0);
+		if (sum != 0) atomicAdd(A.rgb + (size_t)k * A.npix + pixel, (unsigned long long)sum);
+	}
+}
+
 // local pixel number (tile-major, 8x8 blocks inside a 32x8 tile) -> image coordinates
 __device__ __forceinline__ bool tilePixel(uint32_t lp, int W, int H, int rank, int ranks, int& x, int& y) {
 	const uint32_t tilesX = (uint32_t)(W + 31) / 32, tilesY = (uint32_t)(H + 7) / 8;
@@ -456,7 +474,7 @@ struct Tracer;
 struct PacketLds {
 	float4* root;               // [64] the root treelet, shared by the workgroup's waves
 	float4* treelet;            // [levels - 1 (+ 1)][64]: this wave's buffer per deeper treelet level, then the staging buffer
-	uint32_t (*stack)[4];       // [RT_PACKET_STACK_DEPTH]: node, lane mask lo/hi, level (inner) or aux (leaf)
+	uint32_t (*stack)[8];       // [RT_PACKET_STACK_DEPTH] x 32 B: node, lane mask lo/hi, level (inner) or aux (leaf); the two-ray walk uses all 32 B
 	uint32_t staging;           // index of the staging buffer in treelet[]
 	__device__ __forceinline__ float4* level(uint32_t l) const { return l == 0 ? root : treelet + (l - 1u) * 64u; }
 };
@@ -469,7 +487,7 @@ __device__ __forceinline__ PacketLds packetLdsInit(const DevScene& S) {
 	L.root = packetLdsRaw;
 	L.treelet = packetLdsRaw + 64 + (threadIdx.x >> 6) * perWave;
 	L.staging = S.treelet_levels > 1 ? (uint32_t)S.treelet_levels - 1u : 0u;
-	L.stack = reinterpret_cast<uint32_t (*)[4]>(L.treelet + (L.staging + (S.treelet_staging ? 1u : 0u)) * 64u);
+	L.stack = reinterpret_cast<uint32_t (*)[8]>(L.treelet + (L.staging + (S.treelet_staging ? 1u : 0u)) * 64u);
 	if (threadIdx.x < 64 && S.treelet_root >= 0) L.root[threadIdx.x] = S.treelets[threadIdx.x];
 	__syncthreads();
 	return L;
@@ -633,6 +651,122 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 				info = entry.w;
 				inSub = ((m >> lane) & 1ull) != 0 && (!ANYHIT || T.lit);
 				if (__ballot(inSub) != 0) break;   // nobody left who wants this subtree (occluded lanes)
+			}
+		}
+	}
+}
+
+// Two shadow rays per lane: the rays from one surface point towards two lights.  Both start inside the same leaves, so
+// the nodes whose boxes contain the point -- most of what a shadow ray out of a height field visits -- are visited by
+// both, and a step's fixed cost (node fetch, ballots, stack, branches: ~100 of its ~125 instructions) is paid once for the
+// two.  Each ray keeps its own lane masks; every lane still applies the reference's tests to exactly the nodes and
+// primitives its own walk of that ray would reach.  Any-hit only (no visiting order to respect).  A and B hold the same
+// origin.
+template <bool CSG, bool COUNT>
+__device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketLds& L, Trav& A, Trav& B, bool aliveA, bool aliveB) {
+	const uint32_t lane = __lane_id();
+	bool inA = aliveA && A.cur != kEmpty, inB = aliveB && B.cur != kEmpty;
+	if (__ballot(inA || inB) == 0) return;
+	int32_t node = S.treelet_root;
+	uint32_t info = node < 0 ? S.treelet_root_aux : 0u;
+	int sp = 0;
+	uint4* stack = reinterpret_cast<uint4*>(L.stack);   // two uint4 per entry: node, info, -, - | mask A lo/hi, mask B lo/hi
+	for (;;) {
+		node = __builtin_amdgcn_readfirstlane(node);
+		info = __builtin_amdgcn_readfirstlane(info);
+		bool popNext = true;
+		if (node >= 0) {
+			const bool cons = ((uint32_t)node & RT_TREELET_CONS) != 0u;
+			const int32_t nidx = (int32_t)((uint32_t)node & (RT_TREELET_CONS - 1u));
+			float4* buf = L.level(info);
+			if ((nidx & (RT_TREELET_SLOTS - 1)) == 0 && nidx != 0) {
+				buf[lane] = S.treelets[(size_t)nidx * 4 + lane];
+				__builtin_amdgcn_wave_barrier();
+			}
+			const float4* q = buf + (nidx & (RT_TREELET_SLOTS - 1)) * 4;
+			const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+			const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
+			const float b1[6] = { b.z, b.w, c.x, c.y, c.z, c.w };
+			const int32_t c0 = __builtin_amdgcn_readfirstlane(__float_as_int(d.x)), c1 = __builtin_amdgcn_readfirstlane(__float_as_int(d.y));
+			const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(d.z)), x1 = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(d.w));
+			float t;
+			bool h0A, h1A, h0B, h1B, a0A, a1A, a0B, a1B;
+			boxClassifyFlat(b0, A.e, A.inv, 1.0f, t, h0A, a0A);
+			boxClassifyFlat(b1, A.e, A.inv, 1.0f, t, h1A, a1A);
+			boxClassifyFlat(b0, A.e, B.inv, 1.0f, t, h0B, a0B);
+			boxClassifyFlat(b1, A.e, B.inv, 1.0f, t, h1B, a1B);
+			h0A = h0A && inA && !A.special; h1A = h1A && inA && !A.special;
+			a0A = (a0A || A.special) && inA; a1A = (a1A || A.special) && inA;
+			h0B = h0B && inB && !B.special; h1B = h1B && inB && !B.special;
+			a0B = (a0B || B.special) && inB; a1B = (a1B || B.special) && inB;
+			if (COUNT) { A.cntNodes += inA ? 1u : 0u; B.cntNodes += inB ? 1u : 0u; }
+			if (cons) { h0A = h0A || a0A; h1A = h1A || a1A; h0B = h0B || a0B; h1B = h1B || a1B; }
+			else if (__ballot(a0A || a1A || a0B || a1B) != 0) {   // too close to call somewhere (rare): the reference's own arithmetic decides
+				if (a0A) { const float tt = boxIntersect(b0, A.e, A.d, false); h0A = !(tt < 0 || tt > 1.0f); }
+				if (a1A) { const float tt = boxIntersect(b1, A.e, A.d, false); h1A = !(tt < 0 || tt > 1.0f); }
+				if (a0B) { const float tt = boxIntersect(b0, A.e, B.d, false); h0B = !(tt < 0 || tt > 1.0f); }
+				if (a1B) { const float tt = boxIntersect(b1, A.e, B.d, false); h1B = !(tt < 0 || tt > 1.0f); }
+			}
+			const unsigned long long m0A = __ballot(h0A), m1A = __ballot(h1A), m0B = __ballot(h0B), m1B = __ballot(h1B);
+			const uint32_t i0 = c0 < 0 ? x0 : info + (((((uint32_t)c0 & (RT_TREELET_CONS - 1u)) ^ (uint32_t)nidx) >> 4) != 0);
+			const uint32_t i1 = c1 < 0 ? x1 : info + (((((uint32_t)c1 & (RT_TREELET_CONS - 1u)) ^ (uint32_t)nidx) >> 4) != 0);
+			const bool any0 = (m0A | m0B) != 0, any1 = (m1A | m1B) != 0;
+			if (any0 && any1) {
+				if (sp < RT_PACKET_STACK_DEPTH) {
+					stack[2 * sp] = make_uint4((uint32_t)c1, i1, 0u, 0u);
+					stack[2 * sp + 1] = make_uint4((uint32_t)m1A, (uint32_t)(m1A >> 32), (uint32_t)m1B, (uint32_t)(m1B >> 32));
+					sp++;
+				}
+				node = c0; info = i0; inA = h0A; inB = h0B; popNext = false;
+			} else if (any0) { node = c0; info = i0; inA = h0A; inB = h0B; popNext = false; }
+			else if (any1) { node = c1; info = i1; inA = h1A; inB = h1B; popNext = false; }
+		} else if (info != RT_TREELET_NO_RUN) {
+			const bool longRun = (info >> 26) == 0u;
+			const uint32_t count = longRun ? info : info >> 26;
+			const uint32_t key0 = (uint32_t)~node + 1u;
+			if (!longRun && (info & RT_TREELET_EMBED)) {
+				const float4* q = L.level((info >> 4) & 15u) + (info & 15u) * 4u;
+				for (uint32_t k = 0; k < count; k++, q += 4) {
+					const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+					packetTri<true, COUNT>(S, A, inA, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), __float_as_uint(d.w));
+					packetTri<true, COUNT>(S, B, inB, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), __float_as_uint(d.w));
+				}
+			} else {
+				const uint32_t first = longRun ? (uint32_t)~node : info & (RT_TREELET_EMBED - 1u);
+				float4* buf = L.treelet + L.staging * 64u;
+				for (uint32_t k0 = 0; k0 < count; k0 += 16u) {
+					const uint32_t nb = count - k0 < 16u ? count - k0 : 16u;
+					if (lane < nb * 4u) buf[lane] = reinterpret_cast<const float4*>(S.tris + first + k0)[lane];
+					__builtin_amdgcn_wave_barrier();
+					for (uint32_t k = 0; k < nb; k++) {
+						const float4 a = buf[4 * k], b = buf[4 * k + 1], c = buf[4 * k + 2], d = buf[4 * k + 3];
+						packetTri<true, COUNT>(S, A, inA, a, b, c, first + k0 + k, __float_as_int(d.y), key0 + k0 + k);
+						packetTri<true, COUNT>(S, B, inB, a, b, c, first + k0 + k, __float_as_int(d.y), key0 + k0 + k);
+					}
+					__builtin_amdgcn_wave_barrier();
+				}
+			}
+		} else {
+			int32_t at = ~node;
+			for (;;) {
+				const uint32_t entry = *(cuint32*)(uintptr_t)(S.leaf_prims + at);
+				packetPrim<true, CSG, COUNT>(S, A, inA, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u);
+				packetPrim<true, CSG, COUNT>(S, B, inB, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u);
+				if (entry & RT_PRIM_LAST) break;
+				at++;
+			}
+		}
+		if (popNext) {
+			for (;;) {
+				if (sp == 0) return;
+				sp--;
+				const uint4 e0 = stack[2 * sp], e1 = stack[2 * sp + 1];
+				const unsigned long long mA = (unsigned long long)e1.x | ((unsigned long long)e1.y << 32), mB = (unsigned long long)e1.z | ((unsigned long long)e1.w << 32);
+				node = (int32_t)e0.x;
+				info = e0.y;
+				inA = ((mA >> lane) & 1ull) != 0 && A.lit;
+				inB = ((mB >> lane) & 1ull) != 0 && B.lit;
+				if (__ballot(inA || inB) != 0) break;
 			}
 		}
 	}
@@ -1209,8 +1343,10 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq,
 // Packet form of k_shadow_point for coherent surface sets: 64 consecutive surfaces towards the same light.  Only the
 // surface point is held during the walk; the rest of the surface record is read when the ray turned out lit.
 template <bool CSG, bool COUNT>
-__global__ __launch_bounds__(kBlock, RT_SHADOW_WAVES_PER_SIMD) void k_shadow_point_packet(DevScene S, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
-                                                                RtAccum A, uint32_t aaSq, RtCounters* ctr) {
+__global__ __launch_bounds__(kBlock, RT_SHADOW_WAVES_PER_SIMD) void k_shadow_point_packet(DevScene S, RtQueue sq, uint32_t nsurfArg, const int32_t* lightList, uint32_t nLights,
+                                                                RtAccum A, uint32_t aaSq, RtCounters* ctr, int countOnDevice) {
+	// countOnDevice: the launch was queued before the host knew how many surfaces the shading kernel made (nsurfArg is only a bound)
+	const uint32_t nsurf = countOnDevice ? (ctr->surf_count < sq.cap ? ctr->surf_count : sq.cap) : nsurfArg;
 	const uint32_t lane = __lane_id();
 	const PacketLds ws = packetLdsInit(S);
 	const uint32_t packetsPerLight = (nsurf + 63u) / 64u;
@@ -1262,6 +1398,65 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW_WAVES_PER_SIMD) void k_shadow_poi
 		WL_PACKET(T, alive);
 	}
 	WL_END();
+	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
+}
+
+// Two lights per packet (packetTraverse2): lights lightList[2j] and lightList[2j + 1] for the same 64 surfaces; the surface
+// record is read once and the two contributions reach the pixel as one atomic per channel.
+template <bool CSG, bool COUNT>
+__global__ __launch_bounds__(kBlock, RT_SHADOW2_WAVES_PER_SIMD) void k_shadow_point_packet2(DevScene S, RtQueue sq, uint32_t nsurfArg, const int32_t* lightList, uint32_t nPairs,
+                                                                 RtAccum A, uint32_t aaSq, RtCounters* ctr, int countOnDevice) {
+	const uint32_t nsurf = countOnDevice ? (ctr->surf_count < sq.cap ? ctr->surf_count : sq.cap) : nsurfArg;
+	const uint32_t lane = __lane_id();
+	const PacketLds ws = packetLdsInit(S);
+	const uint32_t totalPackets = ((nsurf + 63u) / 64u) * nPairs;
+	unsigned long long cn = 0, cp = 0;
+	PacketFeed feed = firstPackets(totalPackets);
+	uint32_t q = feed.next < feed.end ? feed.next++ : kInactive;
+	while (q != kInactive) {
+		const uint32_t s = (q / nPairs) * 64u + lane;
+		const int lightA = lightList[2u * (q % nPairs)], lightB = lightList[2u * (q % nPairs) + 1u];
+		const bool alive = s < nsurf;
+		f3 p = mk3(0, 0, 0);
+		if (alive) p = mk3(qf(sq, SQ_PX, s), qf(sq, SQ_PY, s), qf(sq, SQ_PZ, s));
+		Trav TA, TB;
+		TA.cur = kEmpty; TA.lit = true; TA.shadow = mk3(1.0f, 1.0f, 1.0f); TA.cntNodes = 0; TA.cntPrims = 0;
+		TB.cur = kEmpty; TB.lit = true; TB.shadow = mk3(1.0f, 1.0f, 1.0f); TB.cntNodes = 0; TB.cntPrims = 0;
+		if (alive) {
+			f3 Ld, lightPos;
+			pointLightGeometry(S.lights[lightA], p, Ld, lightPos);
+			travInit<true>(S, TA, p, lightPos - p);   // bvh.cpp:124
+			pointLightGeometry(S.lights[lightB], p, Ld, lightPos);
+			travInit<true>(S, TB, p, lightPos - p);
+		}
+		packetTraverse2<CSG, COUNT>(S, ws, TA, TB, alive, alive);
+		q = fetchPacket(feed, &ctr->head_shadow, totalPackets);
+		if (COUNT) { cn += TA.cntNodes + TB.cntNodes; cp += TA.cntPrims + TB.cntPrims; }
+		if (alive && (TA.lit || TB.lit)) {
+			const Surface sf = loadSurface(sq, s);
+			f3 cA = mk3(0, 0, 0), cB = cA;
+			bool hasA = false, hasB = false;
+			if (TA.lit) {
+				const rt_light L = S.lights[lightA];
+				f3 Ld, lightPos;
+				pointLightGeometry(L, sf.p, Ld, lightPos);
+				if (!(L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff))) {   // objects.cpp:451
+					cA = sf.w * phong(ld3(L.colour) * TA.shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
+					hasA = true;
+				}
+			}
+			if (TB.lit) {
+				const rt_light L = S.lights[lightB];
+				f3 Ld, lightPos;
+				pointLightGeometry(L, sf.p, Ld, lightPos);
+				if (!(L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff))) {
+					cB = sf.w * phong(ld3(L.colour) * TB.shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
+					hasB = true;
+				}
+			}
+			accumAdd2(A, sf.pixKey / aaSq, cA, hasA, cB, hasB);
+		}
+	}
 	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
 }
 
@@ -1467,12 +1662,21 @@ void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint3
 	else hipLaunchKernelGGL((k_transmit<true, false, false>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
 }
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
-                      RtAccum A, uint32_t aaSq, RtCounters* ctr) {
+                      RtAccum A, uint32_t aaSq, RtCounters* ctr, bool countOnDevice, int maxBlocksPairs) {
+	const int cod = countOnDevice ? 1 : 0;   // packet kernels only: nsurf is a bound, the kernels read the count from ctr
 	const unsigned long long items = (unsigned long long)nsurf * nLights;
+	static const bool noPairs = getenv("RT_NO_LIGHT_PAIRS") != nullptr;
+	if (coherent && nLights >= 2 && nLights % 2 == 0 && !noPairs) {   // two lights per packet
+		const uint32_t nPairs = nLights / 2;
+		const unsigned long long pitems = (unsigned long long)((nsurf + 63u) / 64u) * 64u * nPairs;
+		if (csg) { if (count) RT_LAUNCH_PS((k_shadow_point_packet2<true, true>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet2<true, false>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); }
+		else { if (count) RT_LAUNCH_PS((k_shadow_point_packet2<false, true>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet2<false, false>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); }
+		return;
+	}
 	if (coherent) {
 		const unsigned long long pitems = (unsigned long long)((nsurf + 63u) / 64u) * 64u * nLights;
-		if (csg) { if (count) RT_LAUNCH_PS((k_shadow_point_packet<true, true>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_PS((k_shadow_point_packet<true, false>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
-		else { if (count) RT_LAUNCH_PS((k_shadow_point_packet<false, true>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_PS((k_shadow_point_packet<false, false>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
+		if (csg) { if (count) RT_LAUNCH_PS((k_shadow_point_packet<true, true>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet<true, false>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); }
+		else { if (count) RT_LAUNCH_PS((k_shadow_point_packet<false, true>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet<false, false>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); }
 		return;
 	}
 	if (csg) { if (count) RT_LAUNCH_P((k_shadow_point<true, true>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_P((k_shadow_point<true, false>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }

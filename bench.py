@@ -192,7 +192,8 @@ def main():
                       counted["rays_nearest"] * (RAY_QUEUE_BYTES + HIT_QUEUE_BYTES))
         shad_bytes = (counted["nodes_shadow"] * NODE_BYTES + counted["prims_shadow"] * TRI_BYTES + counted["rays_shadow"] * SURF_BYTES)
         if shad_ms >= near_ms:
-            kname, ms, nbytes = "k_shadow_point_packet", shad_ms, shad_bytes
+            # two point-type lights: the two-rays-per-lane form of the shadow packet kernel
+            kname, ms, nbytes = "k_shadow_point_packet2", shad_ms, shad_bytes
         else:
             kname, ms, nbytes = "k_intersect_packet", near_ms, near_bytes
         achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

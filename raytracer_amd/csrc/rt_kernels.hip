@@ -18,8 +18,9 @@
 //   k_shade                 Object::lightPoint objects.cpp:54-105 minus the shadow rays: normals (bump.cpp), textures
 //                           (texturemesh.cpp), ambient term, reflected children, requests for transmitted children
 //   k_transmit              Object::transmitRay objects.cpp:107-140 over the compacted requests (64-thread blocks)
-//   k_shadow_point_packet,  Directional/Point/Spot::lightPoint objects.cpp:399-458 -> BVH::calcShadow bvh.cpp:123-160,
-//   k_shadow_point          packet and per-lane form
+//   k_shadow_point_packet2, Directional/Point/Spot::lightPoint objects.cpp:399-458 -> BVH::calcShadow bvh.cpp:123-160:
+//   k_shadow_point_packet,  packets with two lights per surface (two rays per lane), with one, and the per-lane form
+//   k_shadow_point
 //   k_shadow_area           AreaLight::lightPoint arealight.cpp:7-22, one lane per sample, segmented wave reduction
 //   k_resolve               fixed point -> float RGB (+ the /4 of q1.cpp:140 for supersampling)
 #include "rt_kernels.h"
@@ -1665,7 +1666,7 @@ void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, b
                       RtAccum A, uint32_t aaSq, RtCounters* ctr, bool countOnDevice, int maxBlocksPairs) {
 	const int cod = countOnDevice ? 1 : 0;   // packet kernels only: nsurf is a bound, the kernels read the count from ctr
 	const unsigned long long items = (unsigned long long)nsurf * nLights;
-	static const bool noPairs = getenv("RT_NO_LIGHT_PAIRS") != nullptr;
+	const bool noPairs = getenv("RT_NO_LIGHT_PAIRS") != nullptr;   // (read per call: the tests switch it)
 	if (coherent && nLights >= 2 && nLights % 2 == 0 && !noPairs) {   // two lights per packet
 		const uint32_t nPairs = nLights / 2;
 		const unsigned long long pitems = (unsigned long long)((nsurf + 63u) / 64u) * 64u * nPairs;

@@ -267,3 +267,32 @@ def test_meshes_asked_for_hits_on_their_own(tmp_path):
     img = sc.render(W, H, camera=cam)
     assert np.abs(rgb8(img.reshape(-1, 3)).astype(int) - rgb8(o["rgb"]).astype(int)).max(axis=1).mean() < 0.01
     sc.close()
+
+
+def test_light_pairs_and_single_light_packets_agree(tmp_path, monkeypatch):
+    """Shadow packets with two lights per surface (two rays per lane) against one light per packet and against the oracle:
+    four point-type lights (two pairs), then three (no pairing), on a scene with transmissive occluders."""
+    import json
+    path = scenes.random_scene(str(tmp_path), seed=38)
+    scene = json.load(open(path))
+    scene["lights"] = [l for l in scene["lights"] if l["type"] in ("ambient", "directional", "point")]
+    scene["lights"] += [{"type": "point", "color": [0.3, 0.5, 0.4], "position": [-2.5, 3.5, -9.0]},
+                        {"type": "spot", "color": [0.6, 0.5, 0.3], "position": [2.0, 4.0, -1.0], "direction": [-0.2, -1.0, -0.6], "cutoff": 40}]
+    for n_lights in (5, 4):                                 # ambient + 4 / + 3 point-type lights
+        scene["lights"] = scene["lights"][:n_lights]
+        p = str(tmp_path / f"lights{n_lights}.json")
+        json.dump(scene, open(p, "w"))
+        flat = rt.FlatScene.from_json(p)
+        sc = rt.Scene(flat, 0)
+        W, H = 256, 144
+        cam = rt.Camera(flat.fov, W, H, eye=(0, 1.0, 1.5), rot_x=-0.2)
+        paired = sc.render(W, H, camera=cam, max_depth=4)
+        st = dict(sc.last_stats)
+        monkeypatch.setenv("RT_NO_LIGHT_PAIRS", "1")
+        single = sc.render(W, H, camera=cam, max_depth=4)
+        monkeypatch.delenv("RT_NO_LIGHT_PAIRS")
+        assert np.abs(paired - single).max() < 1e-6 and sc.last_stats["rays_shadow"] == st["rays_shadow"]
+        ref, nn, ns = oracle.render(flat, cam, W, H, max_depth=4, seed=1, threads=8)
+        assert st["rays_nearest"] == nn and st["rays_shadow"] == ns
+        assert (np.abs(rgb8(paired).astype(int) - rgb8(ref).astype(int)).max(axis=2) > 1).mean() < 1e-3
+        sc.close()

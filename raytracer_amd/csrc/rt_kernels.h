@@ -80,7 +80,8 @@ struct RtCounters {
 	uint32_t head_nearest;    // work cursors of the persistent kernels
 	uint32_t head_shadow;
 	uint32_t trans_count;     // transmission requests appended by k_shade, consumed by k_transmit
-	uint32_t reserved[3];     // ---- everything above is reset at the start of every level (RT_COUNTER_RESET_BYTES) ----
+	uint32_t head_shadow_odd; // cursor of the single-light packet launch that follows the paired one when the lights are odd in number
+	uint32_t reserved[2];     // ---- everything above is reset at the start of every level (RT_COUNTER_RESET_BYTES) ----
 	uint32_t overflow;        // an append found its queue full (the batch is re-run in halves)
 	uint32_t pad;
 	unsigned long long nodes_nearest, prims_nearest;   // RT_FLAG_COUNTERS: 64 B nodes read / primitive tests in k_intersect

@@ -1345,7 +1345,8 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq,
 // surface point is held during the walk; the rest of the surface record is read when the ray turned out lit.
 template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(kBlock, RT_SHADOW_WAVES_PER_SIMD) void k_shadow_point_packet(DevScene S, RtQueue sq, uint32_t nsurfArg, const int32_t* lightList, uint32_t nLights,
-                                                                RtAccum A, uint32_t aaSq, RtCounters* ctr, int countOnDevice) {
+                                                                RtAccum A, uint32_t aaSq, RtCounters* ctr, int countOnDevice, int oddCursor) {
+	uint32_t* const head = oddCursor ? &ctr->head_shadow_odd : &ctr->head_shadow;
 	// countOnDevice: the launch was queued before the host knew how many surfaces the shading kernel made (nsurfArg is only a bound)
 	const uint32_t nsurf = countOnDevice ? (ctr->surf_count < sq.cap ? ctr->surf_count : sq.cap) : nsurfArg;
 	const uint32_t lane = __lane_id();
@@ -1382,7 +1383,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW_WAVES_PER_SIMD) void k_shadow_poi
 		TR(2, __popcll(__ballot(T.cur != kEmpty)));
 		packetTraverse<true, CSG, COUNT>(S, ws, T, alive TR_ARG);
 		TR(9, 0);
-		q = fetchPacket(feed, &ctr->head_shadow, totalPackets);
+		q = fetchPacket(feed, head, totalPackets);
 		TR(10, 0);
 		if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
 		if (alive && T.lit) {
@@ -1667,17 +1668,23 @@ void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, b
 	const int cod = countOnDevice ? 1 : 0;   // packet kernels only: nsurf is a bound, the kernels read the count from ctr
 	const unsigned long long items = (unsigned long long)nsurf * nLights;
 	const bool noPairs = getenv("RT_NO_LIGHT_PAIRS") != nullptr;   // (read per call: the tests switch it)
-	if (coherent && nLights >= 2 && nLights % 2 == 0 && !noPairs) {   // two lights per packet
+	if (coherent && nLights >= 2 && !noPairs) {   // two lights per packet; an odd last one in a launch of its own (with its own cursor)
 		const uint32_t nPairs = nLights / 2;
 		const unsigned long long pitems = (unsigned long long)((nsurf + 63u) / 64u) * 64u * nPairs;
+		if (nLights % 2) {
+			const unsigned long long oitems = (unsigned long long)((nsurf + 63u) / 64u) * 64u;
+			const int32_t* last = lightList + (nLights - 1);
+			if (csg) { if (count) RT_LAUNCH_PS((k_shadow_point_packet<true, true>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); else RT_LAUNCH_PS((k_shadow_point_packet<true, false>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); }
+			else { if (count) RT_LAUNCH_PS((k_shadow_point_packet<false, true>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); else RT_LAUNCH_PS((k_shadow_point_packet<false, false>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); }
+		}
 		if (csg) { if (count) RT_LAUNCH_PS((k_shadow_point_packet2<true, true>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet2<true, false>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); }
 		else { if (count) RT_LAUNCH_PS((k_shadow_point_packet2<false, true>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet2<false, false>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); }
 		return;
 	}
 	if (coherent) {
 		const unsigned long long pitems = (unsigned long long)((nsurf + 63u) / 64u) * 64u * nLights;
-		if (csg) { if (count) RT_LAUNCH_PS((k_shadow_point_packet<true, true>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet<true, false>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); }
-		else { if (count) RT_LAUNCH_PS((k_shadow_point_packet<false, true>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet<false, false>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); }
+		if (csg) { if (count) RT_LAUNCH_PS((k_shadow_point_packet<true, true>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod, 0); else RT_LAUNCH_PS((k_shadow_point_packet<true, false>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod, 0); }
+		else { if (count) RT_LAUNCH_PS((k_shadow_point_packet<false, true>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod, 0); else RT_LAUNCH_PS((k_shadow_point_packet<false, false>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod, 0); }
 		return;
 	}
 	if (csg) { if (count) RT_LAUNCH_P((k_shadow_point<true, true>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_P((k_shadow_point<true, false>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }

@@ -873,7 +873,7 @@ void rt_scene_free(rt_scene* sc) {
 int rt_render_submit(rt_scene* sc, const rt_camera* camera, int width, int height, int aa_x, int aa_y, int max_depth, int tile_rank, int tile_ranks,
                      uint32_t seed, uint32_t flags, float* rgb_dev, void* stream, uint64_t* ticket) {
 	if (!sc || !camera || !rgb_dev || !ticket || width <= 0 || height <= 0 || aa_x < 1 || aa_x > 16 || aa_y < 1 || aa_y > 16 || max_depth < 0 || max_depth > 30 ||
-	    tile_ranks < 1 || tile_rank < 0 || tile_rank >= tile_ranks || (int64_t)width * height > (1ll << 31) / (aa_x * aa_y)) {
+	    tile_ranks < 1 || tile_rank < 0 || tile_rank >= tile_ranks || (int64_t)width * height * (aa_x * aa_y) >= (1ll << 31)) {
 		rt::set_error("rt_render_submit: bad argument");
 		return RT_EINVAL;
 	}

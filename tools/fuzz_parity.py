@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Fuzzing the trace path against the oracle: random scenes (raytracer_amd.scenes.random_scene), a 256x144 frame of
 camera rays through rt_trace_batch and through the frame path, compared with the CPU restatement.
-usage: tools/fuzz_parity.py [first_seed] [count] [objects per scene] [scale of all lengths]       (needs a GPU; prints one line per seed and a summary)"""
+usage: tools/fuzz_parity.py [first_seed] [count] [objects per scene] [scale of all lengths] [W] [H]      (needs a GPU; prints one line per seed and
+a summary).  From 256 tiles of 32x8 pixels on (e.g. 768x432) the frame is cut into one shard per lane, below that it is one shard."""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -30,7 +31,7 @@ def one(seed, W=256, H=144, depth=6, n_objects=40, scale=1.0):
     e = np.tile(np.array(cam.c.eye[:], np.float32), (W * H, 1))
     r = sc.trace_batch(e, s, max_depth=depth, seed=7)
     st = dict(sc.last_stats)
-    o = oracle.trace_batch(flat, e, s, max_depth=depth, seed=7, threads=8)
+    o = oracle.trace_batch(flat, e, s, max_depth=depth, seed=7, threads=min(16, os.cpu_count() or 1))
     img = sc.render(W, H, camera=cam, max_depth=depth, seed=7)
     detail = ""
     if not np.array_equal(bits(img.reshape(-1, 3)), bits(r["rgb"])):
@@ -59,9 +60,11 @@ if __name__ == "__main__":
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     n_objects = int(sys.argv[3]) if len(sys.argv) > 3 else 40
     scale = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
+    W = int(sys.argv[5]) if len(sys.argv) > 5 else 256
+    H = int(sys.argv[6]) if len(sys.argv) > 6 else 144
     bad = 0
     for seed in range(first, first + count):
-        r = one(seed, n_objects=n_objects, scale=scale)
+        r = one(seed, W=W, H=H, n_objects=n_objects, scale=scale)
         ok = r["ids"] and r["t"] and r["rays"] and r["rgb_bad"] < 2e-3 and r["frame_vs_batch"] < 1e-6
         bad += not ok
         print(f"seed {seed}: {'ok ' if ok else 'BAD'} ids {r['ids']} t {r['t']} rays {r['rays']} rgb>1/255 {r['rgb_bad']:.5f} frame==batch {r['frame_eq_batch']} "

@@ -99,24 +99,44 @@ def main():
     sizes = [pad] * world
     recv = [torch.zeros(n, device=dev, dtype=torch.float32) for n in sizes] if (world > 1 and rank == 0) else None
 
-    def assemble(buf):
-        # tiles -> rank 0 (RCCL gather over xGMI; point-to-point when the tile counts are ragged), then de-interleave
-        scene.tiles_pack(buf.data_ptr(), packed.data_ptr(), W, H, rank, world, stream=stream)
-        if rehearsal:
-            host = rd.gather_packed(packed.cpu(), sizes, rank, world)
-            bufs = [h.to(dev) for h in host] if rank == 0 else None
-        else:
-            bufs = rd.gather_packed(packed, sizes, rank, world, bufs=recv)
-        if rank == 0:
-            for r in range(1, world):
-                scene.tiles_unpack(bufs[r].data_ptr(), buf.data_ptr(), W, H, r, world, stream=stream)
+    # The exchange runs on a stream of its own.  Lane 0 of the renderer works on the caller's stream (torch's current one):
+    # a gather queued there would hold that lane's next shards back until every rank had arrived.  Order is kept with two
+    # events per frame buffer: the side stream starts after the frame is complete (rt_render_wait has waited for it on the
+    # host), and the next frame rendered into the same buffer starts after that buffer's tiles were packed and unpacked.
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    assembled = [None] * D
+
+    def assemble(slot):
+        # tiles -> rank 0 (one grouped RCCL gather over xGMI, every peer sending to the root at once), then de-interleave
+        buf = frames[slot]
+        with torch.cuda.stream(side):
+            scene.tiles_pack(buf.data_ptr(), packed.data_ptr(), W, H, rank, world, stream=side.cuda_stream)
+            if rehearsal:
+                host = rd.gather_packed(packed.cpu(), sizes, rank, world)
+                bufs = [h.to(dev) for h in host] if rank == 0 else None
+            else:
+                bufs = rd.gather_packed(packed, sizes, rank, world, bufs=recv)
+            if rank == 0:
+                for r in range(1, world):
+                    scene.tiles_unpack(bufs[r].data_ptr(), buf.data_ptr(), W, H, r, world, stream=side.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        assembled[slot] = ev
+
+    def buffer_free(slot):
+        """The caller's stream (and with it the frame about to be submitted) waits until the buffer's last exchange is through."""
+        if assembled[slot] is not None:
+            torch.cuda.current_stream(dev).wait_event(assembled[slot])
+            assembled[slot] = None
 
     def step(flags=0, max_depth=rt.MAX_REFLECTIONS):
         """One synchronous frame."""
+        buffer_free(0)
         st = scene.render_into(frame.data_ptr(), W, H, aa=(ax, ay), camera=cam, tile_rank=rank, tile_ranks=world, stream=stream, flags=flags,
                                max_depth=max_depth)
         if world > 1:
-            assemble(frame)
+            assemble(0)
+            side.synchronize()
         return st
 
     def run_steps(k):
@@ -124,16 +144,17 @@ def main():
         rays, pending = 0, []
         def retire():
             nonlocal rays
-            ticket, buf = pending.pop(0)
+            ticket, slot = pending.pop(0)
             st = scene.render_wait(ticket)
             if world > 1:
-                assemble(buf)
+                assemble(slot)
             rays += st["rays_nearest"] + st["rays_shadow"]
         for i in range(k):
             if len(pending) == D:
                 retire()
-            buf = frames[i % D]
-            pending.append((scene.render_submit(buf.data_ptr(), W, H, aa=(ax, ay), camera=cam, tile_rank=rank, tile_ranks=world, stream=stream), buf))
+            slot = i % D
+            buffer_free(slot)
+            pending.append((scene.render_submit(frames[slot].data_ptr(), W, H, aa=(ax, ay), camera=cam, tile_rank=rank, tile_ranks=world, stream=stream), slot))
         while pending:
             retire()
         return rays

@@ -974,7 +974,7 @@ int rt_render_host(rt_scene* sc, const rt_camera* camera, int width, int height,
 
 int rt_trace_batch(rt_scene* sc, const float* e, const float* s, size_t n, int max_depth, uint32_t seed, uint32_t flags,
                    uint8_t* hit, int32_t* obj_id, float* t, float* rgb, rt_stats* stats) {
-	if (!sc || !e || !s || max_depth < 0 || max_depth > 30 || n > (1ull << 31)) { rt::set_error("rt_trace_batch: bad argument"); return RT_EINVAL; }
+	if (!sc || (n > 0 && (!e || !s)) || max_depth < 0 || max_depth > 30 || n > (1ull << 31)) { rt::set_error("rt_trace_batch: bad argument"); return RT_EINVAL; }
 	if (stats) memset(stats, 0, sizeof *stats);
 	if (n == 0) return RT_OK;
 	sc->drain();   // the lanes' queues are used directly below
@@ -1043,7 +1043,7 @@ int rt_trace_pick(rt_scene* sc, const float* e, const float* s, int max_depth, u
 }
 
 int rt_intersect_batch(rt_scene* sc, const float* e, const float* d, size_t n, uint32_t flags, uint8_t* hit, int32_t* obj_id, float* t, rt_stats* stats) {
-	if (!sc || !e || !d || n > (1ull << 31)) { rt::set_error("rt_intersect_batch: bad argument"); return RT_EINVAL; }
+	if (!sc || (n > 0 && (!e || !d)) || n > (1ull << 31)) { rt::set_error("rt_intersect_batch: bad argument"); return RT_EINVAL; }
 	if (stats) memset(stats, 0, sizeof *stats);
 	if (n == 0) return RT_OK;
 	sc->drain();   // the lanes' queues are used directly below
@@ -1077,7 +1077,7 @@ int rt_intersect_batch(rt_scene* sc, const float* e, const float* d, size_t n, u
 }
 
 int rt_shadow_batch(rt_scene* sc, const float* point, const float* light_pos, size_t n, uint32_t flags, uint8_t* lit, float* shadow, rt_stats* stats) {
-	if (!sc || !point || !light_pos || n > (1ull << 31)) { rt::set_error("rt_shadow_batch: bad argument"); return RT_EINVAL; }
+	if (!sc || (n > 0 && (!point || !light_pos)) || n > (1ull << 31)) { rt::set_error("rt_shadow_batch: bad argument"); return RT_EINVAL; }
 	if (stats) memset(stats, 0, sizeof *stats);
 	if (n == 0) return RT_OK;
 	sc->drain();   // the lanes' queues are used directly below

@@ -22,6 +22,16 @@
 // sample points.
 #include "restate.h"
 
+#include <atomic>
+#include <unordered_map>
+
+// exit searches of transmitted rays that found no exit (the "STATE" cases above), since the last reset
+static std::atomic<uint64_t> g_stateCases{0};
+// Textured triangles lit with another hit's texel (see trace() below), since the last reset; and whether that behaviour of the
+// reference is reproduced (default) or every hit is lit with its own texel (what the device's wavefront pipeline does).
+static std::atomic<uint64_t> g_texelCases{0};
+static std::atomic<int> g_texelState{1};
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -525,12 +535,14 @@ struct Tracer {
 		while (!result && reflections < RT_MAX_REFLECTIONS) {
 			// rayhit(currentPoint, innerVector, true); outPoint = cachedHitpoint; getNormal(outNormal)
 			V3 hp = currentPoint;   // STATE: a failed exit search leaves an older cachedHitpoint in the reference; fixed fallback here
+			float tExit = 0;
 			switch (type) {
-			case RT_PRIM_SPHERE: { const rt_sphere& s = S->spheres[ix]; sphereHit(V3(s.center), s.radius, currentPoint, innerVector, true, hp); outNormal = sphereNormal(s, hp); break; }
-			case RT_PRIM_TRI: { V3 nrm = outNormal; meshHit(S->meshes[S->tris[ix].mesh], currentPoint, innerVector, true, hp, nrm); outNormal = nrm; break; }   // STATE: cachedHitNormal
-			case RT_PRIM_BOX: boxHit(S->boxes[ix].b, currentPoint, innerVector, true, hp); boxNormal(S->boxes[ix].b, hp, outNormal); break;
-			case RT_PRIM_CSG: { V3 nrm = outNormal; csgHit(S->csgs[ix], currentPoint, innerVector, true, hp, nrm); outNormal = nrm; break; }   // STATE on a miss
+			case RT_PRIM_SPHERE: { const rt_sphere& s = S->spheres[ix]; tExit = sphereHit(V3(s.center), s.radius, currentPoint, innerVector, true, hp); outNormal = sphereNormal(s, hp); break; }
+			case RT_PRIM_TRI: { V3 nrm = outNormal; tExit = meshHit(S->meshes[S->tris[ix].mesh], currentPoint, innerVector, true, hp, nrm); outNormal = nrm; break; }   // STATE: cachedHitNormal
+			case RT_PRIM_BOX: tExit = boxHit(S->boxes[ix].b, currentPoint, innerVector, true, hp); boxNormal(S->boxes[ix].b, hp, outNormal); break;
+			case RT_PRIM_CSG: { V3 nrm = outNormal; tExit = csgHit(S->csgs[ix], currentPoint, innerVector, true, hp, nrm); outNormal = nrm; break; }   // STATE on a miss
 			}
+			if (!(tExit > 0)) g_stateCases.fetch_add(1, std::memory_order_relaxed);   // counted, not hidden: oracle_state_cases()
 			outPoint = hp;
 			result = refractRay(innerVector, outNormal, m.refraction, outVector);
 			if (!result) {
@@ -544,6 +556,8 @@ struct Tracer {
 		return result;
 	}
 
+	std::unordered_map<uint32_t, V3> texelOf;   // TextureTriangle::material.ambient / .diffuse as the last lightPoint on it left them
+
 	// ---- trace raytracer.cpp:307-329 + Object::lightPoint objects.cpp:54-105 + TextureTriangle::lightPoint texturemesh.cpp:25-52 ----
 	bool trace(V3 e, V3 s, V3& colour, int reflectionCount, uint32_t path, Hit* firstHit) {
 		if (reflectionCount > maxDepth) { colour = V3(0, 0, 0); return false; }
@@ -555,6 +569,7 @@ struct Tracer {
 		uint32_t type = RT_PRIM_TYPE(hit.prim), ix = RT_PRIM_INDEX(hit.prim);
 		rt_material material = S->materials[primMaterial(hit.prim)];
 		V3 p = hit.point;
+		bool textured = false;
 
 		if (type == RT_PRIM_TRI && S->tris[ix].uv >= 0) {   // TextureTriangle::lightPoint
 			const rt_tri& tr = S->tris[ix];
@@ -573,6 +588,8 @@ struct Tracer {
 			V3 texColour(float(px[0]) / 255, float(px[1]) / 255, float(px[2]) / 255);
 			material.ambient[0] = texColour.x; material.ambient[1] = texColour.y; material.ambient[2] = texColour.z;
 			material.diffuse[0] = texColour.x; material.diffuse[1] = texColour.y; material.diffuse[2] = texColour.z;
+			texelOf[ix] = texColour;   // texturemesh.cpp:49-50 writes the TRIANGLE's own material: state that outlives this call
+			textured = true;
 		}
 
 		V3 V = normalize(-d);
@@ -592,6 +609,17 @@ struct Tracer {
 			bool h = trace(p + float(1e-5) * R, p + R, colour, reflectionCount + 1, path * 2, nullptr);
 			if (!h) colour = V3(S->background);
 			colour = colour * V3(material.reflective);
+			// The reflected ray's subtree may have come back to this very triangle (two reflective meshes facing each other): its
+			// lightPoint overwrote material.ambient / .diffuse (texturemesh.cpp:49-50), and the lights below (objects.cpp:77-79) read
+			// the member, i.e. the texel of the LAST hit on the triangle -- state of this ray tree only, since every hit sets it first.
+			if (textured && g_texelState.load(std::memory_order_relaxed)) {
+				const V3 cur = texelOf[ix];
+				if (cur.x != material.diffuse[0] || cur.y != material.diffuse[1] || cur.z != material.diffuse[2]) {
+					g_texelCases.fetch_add(1, std::memory_order_relaxed);
+					material.ambient[0] = cur.x; material.ambient[1] = cur.y; material.ambient[2] = cur.z;
+					material.diffuse[0] = cur.x; material.diffuse[1] = cur.y; material.diffuse[2] = cur.z;
+				}
+			}
 		}
 		for (int i = 0; i < S->n_lights; i++) lightPoint(S->lights[i], i, path, p, N, V, material, colour);
 		if (!isZero(material.transmissive)) {
@@ -712,6 +740,20 @@ int oracle_render(const rt_flat_scene* scene, const rt_camera* camera, int width
 	}
 	if (counts) for (size_t k = 0; k < cn.size(); k++) { counts[0] += cn[k]; counts[1] += cs[k]; }
 	return 0;
+}
+
+uint64_t oracle_texel_cases(int reset) {
+	const uint64_t n = g_texelCases.load();
+	if (reset) g_texelCases.store(0);
+	return n;
+}
+
+int oracle_texel_state(int on) { return g_texelState.exchange(on ? 1 : 0); }
+
+uint64_t oracle_state_cases(int reset) {
+	const uint64_t n = g_stateCases.load();
+	if (reset) g_stateCases.store(0);
+	return n;
 }
 
 }  // extern "C"

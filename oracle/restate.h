@@ -40,6 +40,19 @@ int oracle_render(const rt_flat_scene* scene, const rt_camera* camera, int width
                   float* rgb, uint64_t counts[2], int threads);
 
 /* primary ray targets s(x,y) / s_aa (q1.cpp:51-64) for sample k of the n x n grid, into out[3] */
+/* Number of exit searches of transmitted rays (Object::transmitRay, objects.cpp:119-125) that found no exit since the last reset: there the
+ * reference goes on from Object::cachedHitpoint as an EARLIER ray left it, which no stateless program can follow; the restatement (and the
+ * device) use a fixed fallback.  Rays that ran into one are the only ones allowed to differ from the compiled reference. */
+uint64_t oracle_state_cases(int reset);
+
+/* TextureTriangle::lightPoint writes the texel into the triangle's own material (texturemesh.cpp:49-50) and Object::lightPoint reads the member
+ * AFTER it has traced the reflected ray (objects.cpp:62-79): when that ray's subtree comes back to the same triangle, the outer hit is lit with
+ * the texel of the last hit on it.  The restatement reproduces this (it is state of one ray tree only); oracle_texel_cases counts the hits it
+ * changed since the last reset, and oracle_texel_state(0) switches it off -- every hit lit with its own texel, which is what the device's
+ * level-by-level pipeline computes -- returning the previous setting. */
+uint64_t oracle_texel_cases(int reset);
+int oracle_texel_state(int on);
+
 void oracle_primary_target(const rt_camera* camera, int width, int height, int x, int y, int aa_x, int aa_y, int k, float out[3]);
 
 #ifdef __cplusplus

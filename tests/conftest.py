@@ -11,6 +11,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 GOLD = os.path.join(ROOT, "tests", "golden")
 SCENES_DET = "abcdefghijkl"     # deterministic bundled scenes; m has rand()-driven area lights
+# the compiled reference on scenes of raytracer_amd.scenes.random_scene (tools/make_random_golden.py): everything at once, 96x64
+SCENES_RANDOM = ("random_5", "random_8")
 
 
 def pytest_configure(config):

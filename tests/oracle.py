@@ -19,6 +19,29 @@ def lib():
     return _lib
 
 
+class own_texels:
+    """Inside this context the restatement lights every hit on a textured triangle with its own texel -- what the device's level-by-level
+    pipeline computes -- instead of reproducing the reference's texel state (oracle/restate.h: oracle_texel_state)."""
+    def __enter__(self):
+        self.prev = lib().oracle_texel_state(0)
+    def __exit__(self, *exc):
+        lib().oracle_texel_state(self.prev)
+
+
+def texel_cases(reset=True):
+    """Hits the restatement lit with another hit's texel since the last reset (oracle_texel_cases)."""
+    f = lib().oracle_texel_cases
+    f.restype = C.c_uint64
+    return int(f(1 if reset else 0))
+
+
+def state_cases(reset=True):
+    """Exit searches of transmitted rays that found no exit since the last reset (oracle_state_cases)."""
+    f = lib().oracle_state_cases
+    f.restype = C.c_uint64
+    return int(f(1 if reset else 0))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

@@ -4,14 +4,14 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import SCENES_DET
+from conftest import SCENES_DET, SCENES_RANDOM
 
 
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("name", list(SCENES_DET))
+@pytest.mark.parametrize("name", list(SCENES_DET) + list(SCENES_RANDOM))
 def test_trace_bit_exact_vs_reference(name, flat_scenes, golden):
     g = golden(name)
     n = int(g["W"]) * int(g["H"])
@@ -23,7 +23,7 @@ def test_trace_bit_exact_vs_reference(name, flat_scenes, golden):
     assert r["rays_nearest"] == int(g["rays_nearest"]) and r["rays_shadow"] == int(g["rays_shadow"])
 
 
-@pytest.mark.parametrize("name", list(SCENES_DET))
+@pytest.mark.parametrize("name", list(SCENES_DET) + list(SCENES_RANDOM))
 def test_secondary_and_shadow_rays_vs_reference(name, flat_scenes, golden):
     g = golden(name)
     fs = flat_scenes(name)
@@ -34,6 +34,25 @@ def test_secondary_and_shadow_rays_vs_reference(name, flat_scenes, golden):
     r = oracle.shadow_batch(fs, g["shd_p"], g["shd_l"])
     assert np.array_equal(r["lit"], g["shd_lit"].astype(np.uint8))
     assert np.array_equal(bits(r["shadow"]), bits(g["shd_shadow"]))
+
+
+def test_texel_state_of_rehit_textured_triangles(flat_scenes, golden):
+    """random_5: two reflective meshes face each other, and a reflected ray's subtree comes back to the textured triangle it left.
+    The reference then lights the outer hit with the texel of the LAST hit on that triangle (texturemesh.cpp:49-50 writes the
+    triangle's own material, objects.cpp:77-79 reads it after the recursion).  The restatement follows (bit-exact above); with
+    that switched off -- the device's behaviour -- exactly the affected pixels change."""
+    g = golden("random_5")
+    n = int(g["W"]) * int(g["H"])
+    fs = flat_scenes("random_5")
+    oracle.texel_cases()
+    exact = oracle.trace_batch(fs, np.zeros((n, 3), np.float32), g["s"], seed=0)
+    assert oracle.texel_cases() == 2
+    with oracle.own_texels():
+        own = oracle.trace_batch(fs, np.zeros((n, 3), np.float32), g["s"], seed=0)
+        assert oracle.texel_cases() == 0
+    differ = (bits(exact["rgb"]) != bits(own["rgb"])).any(axis=1)
+    assert differ.sum() == 2 and np.array_equal(bits(exact["rgb"]), bits(g["rgb"]))
+    assert np.array_equal(exact["id"], own["id"]) and exact["rays_shadow"] == own["rays_shadow"]
 
 
 def test_scene_m_same_rand_stream_is_bit_exact(flat_scenes, golden):

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""tests/golden/ref_random_<seed>.npz + tests/golden/scenes/random_<seed>.rtscene.gz: the COMPILED REFERENCE's output (oracle/_ref/ref_driver,
+`make -C oracle ref`; container only) on scenes of raytracer_amd.scenes.random_scene -- every primitive, material and light kind at once,
+which the thirteen bundled scenes do not offer -- at 96x64 from the default camera, in the format of tools/make_golden.py.  The reference loads
+the generated JSON from a temporary directory (its scene path is the relative literal "scenes/", raytracer.cpp:22).
+usage: tools/make_random_golden.py seed [seed ...]        (seeds whose scene has no area light: those draw from rand())"""
+import ctypes as C
+import gzip
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+from make_golden import GOLD, run_driver  # noqa: E402
+from raytracer_amd import scenes  # noqa: E402
+
+if __name__ == "__main__":
+    lib = C.CDLL(os.path.join(ROOT, "raytracer_amd", "lib", "libraytracer_amd.so"))
+    for seed in (int(a) for a in sys.argv[1:]):
+        with tempfile.TemporaryDirectory() as tmp:
+            path = scenes.random_scene(os.path.join(tmp, "scenes"), seed=seed, n_objects=40)
+            kinds = {l["type"] for l in json.load(open(path))["lights"]}
+            assert not kinds & {"rectangular", "circular"}, f"seed {seed} has an area light (rand()-driven): pick another"
+            r = run_driver(f"random_{seed}", 96, 64, 4096, cwd=tmp)
+            np.savez_compressed(os.path.join(GOLD, f"ref_random_{seed}.npz"), **r)
+            fs = C.c_void_p()
+            assert lib.rt_load_scene_json(path.encode(), None, C.byref(fs)) == 0
+            flat = os.path.join(tmp, "flat.rtscene")
+            assert lib.rt_flat_scene_save(fs, flat.encode()) == 0
+            lib.rt_flat_scene_free(fs)
+            with open(flat, "rb") as f, gzip.GzipFile(os.path.join(GOLD, "scenes", f"random_{seed}.rtscene.gz"), "wb", mtime=0) as g:
+                shutil.copyfileobj(f, g)
+        print(f"random_{seed}: 96x64, {r['rays_nearest']} nearest, {r['rays_shadow']} shadow rays", flush=True)

@@ -9,7 +9,7 @@ rand() in the reference's order (seed 0, one thread) so that area lights compare
 and float RGB bit for bit, the frame's BVH::findNearest / BVH::calcShadow call counts, and the sampled secondary rays and shadow
 queries the driver intercepted.
 
-usage: tools/fuzz_oracle_vs_ref.py [first_seed] [count] [objects per scene] [W] [H]"""
+usage: tools/fuzz_oracle_vs_ref.py [first_seed] [count] [objects per scene] [W] [H] [mixed | csg | <scale factor>]"""
 import ctypes
 import os
 import sys
@@ -29,10 +29,15 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def one(seed, n_objects, W, H):
+def one(seed, n_objects, W, H, kind="mixed"):
     with tempfile.TemporaryDirectory() as tmp:
-        path = scenes.random_scene(os.path.join(tmp, "scenes"), seed=seed, n_objects=n_objects)
-        g = run_driver(f"random_{seed}", W, H, 4096, cwd=tmp)
+        if kind == "csg":       # random operator trees of up to 16 leaves (multi-interval lists, empty operands)
+            path = scenes.random_csg_scene(os.path.join(tmp, "scenes"), seed=seed, n_objects=n_objects)
+        else:
+            path = scenes.random_scene(os.path.join(tmp, "scenes"), seed=seed, n_objects=n_objects)
+            if kind != "mixed":     # every length scaled: the reference's absolute epsilons against tiny / huge geometry
+                path = scenes.scale_scene(path, float(kind))
+        g = run_driver(os.path.basename(path)[:-5], W, H, 4096, cwd=tmp)
         flat = rt.FlatScene.from_json(path)
     n = W * H
     ctypes.CDLL(None).srand(1)
@@ -73,9 +78,10 @@ if __name__ == "__main__":
     n_objects = int(sys.argv[3]) if len(sys.argv) > 3 else 40
     W = int(sys.argv[4]) if len(sys.argv) > 4 else 96
     H = int(sys.argv[5]) if len(sys.argv) > 5 else 64
+    kind = sys.argv[6] if len(sys.argv) > 6 else "mixed"
     exact = explained = pixels = 0
     for seed in range(first, first + count):
-        r = one(seed, n_objects, W, H)
+        r = one(seed, n_objects, W, H, kind)
         same = not (r["differing"] or r["sec"] or r["shd"] or r["rays"] != (0, 0))
         # ray counts may move with a hidden-state pixel (its subtree differs); sampled rays are stateless queries and must agree
         ok = same or (r["unexplained"] == 0 and r["sec"] == 0 and r["shd"] == 0 and r["differing"] > 0)
@@ -85,6 +91,6 @@ if __name__ == "__main__":
         print(f"seed {seed}: {'identical' if same else 'hidden state' if ok else 'DIFFERS'}: {r['differing']} of {W * H} pixels differ (hit {r['hit']} id {r['id']} t {r['t']} rgb {r['rgb']}), "
               f"{r['unexplained']} of them without a failed exit search in their ray tree ({r['frame_cases']} failed exit searches in the frame, {r['texel_cases']} hits lit with a later hit's texel); ray counts {r['rays'][0]:+d} {r['rays'][1]:+d}; "
               f"sampled secondary rays {r['sec']}, shadow queries {r['shd']}  ({r['lights']} lights, {r['nearest']} nearest, {r['shadow']} shadow rays)", flush=True)
-    print(f"{count} random scenes: {exact} bit-identical to the compiled reference, {explained - exact} differ only in pixels whose ray tree holds a failed exit search "
+    print(f"{count} random scenes ({kind}): {exact} bit-identical to the compiled reference, {explained - exact} differ only in pixels whose ray tree holds a failed exit search "
           f"({pixels} pixels of {count * W * H} in all), {count - explained} differ otherwise")
     sys.exit(0 if explained == count else 1)

@@ -41,6 +41,11 @@ struct rt_scene {
 	DevScene dev{};
 	bool hasCsg = false;
 	bool hasTransmissive = false;   // some material transmits: k_shade queues requests for k_transmit
+	// some textured triangle reflects: its hits leave records for k_texel_fix (RtTexFix in rt_kernels.h).  The per-pixel list heads
+	// are shared by the lanes like the accumulators (shards own disjoint pixels), the records are per lane.
+	bool texelFix = false;
+	uint32_t* texHeads = nullptr;
+	uint32_t texCap = 0;
 	std::vector<void*> allocs;
 	// lights, split by how their shadow rays are generated
 	int32_t* pointLights = nullptr;
@@ -57,7 +62,9 @@ struct rt_scene {
 		RtCounters* ctrHost = nullptr;   // pinned
 		hipEvent_t ev[6]{};              // 0,1 whole call; 2,3 nearest kernel; 4,5 shadow kernels
 		hipStream_t stream = nullptr;    // owned, non-blocking (lane 0 also runs on the caller's stream)
+		RtTexRec* texRec = nullptr;      // texelFix only
 	};
+	RtTexFix texFix(const Lane& ln) const { return RtTexFix{ texelFix ? ln.texRec : nullptr, texHeads, texCap }; }
 	uint32_t qcap = 0;
 	int maxBlocks = 2048;            // grid cap of the persistent kernels
 	int maxBlocksPacketNear = 2048;  // ... of the nearest-hit packet kernel (see rt_scene_upload)
@@ -117,6 +124,11 @@ struct rt_scene {
 		if (int rc = allocQueue(ln.surfq, SQ_COMPS)) return rc;
 		if (hasTransmissive) { if (int rc = allocQueue(ln.transq, TQ_COMPS)) return rc; }
 		void* p = nullptr;
+		if (texelFix) {
+			HIPCHK(hipMalloc(&p, (size_t)texCap * sizeof(RtTexRec)));
+			allocs.push_back(p);
+			ln.texRec = static_cast<RtTexRec*>(p);
+		}
 		HIPCHK(hipMalloc(&p, sizeof(RtCounters)));
 		allocs.push_back(p);
 		ln.ctr = static_cast<RtCounters*>(p);
@@ -132,6 +144,11 @@ struct rt_scene {
 	int ensureAccum(uint32_t npix) {
 		if (accum.npix >= npix && accum.rgb) return RT_OK;
 		if (accum.rgb) { (void)hipFree(accum.rgb); (void)hipFree(accum.nonfinite); accum.rgb = nullptr; accum.nonfinite = nullptr; accum.npix = 0; }
+		if (texHeads) { (void)hipFree(texHeads); texHeads = nullptr; }
+		if (texelFix) {
+			HIPCHK(hipMalloc((void**)&texHeads, (size_t)npix * sizeof(uint32_t)));
+			HIPCHK(hipMemset(texHeads, 0xff, (size_t)npix * sizeof(uint32_t)));   // every list empty
+		}
 		HIPCHK(hipMalloc((void**)&accum.rgb, (size_t)npix * 3 * sizeof(unsigned long long)));
 		HIPCHK(hipMalloc((void**)&accum.nonfinite, (size_t)npix));
 		HIPCHK(hipMemset(accum.rgb, 0, (size_t)npix * 3 * sizeof(unsigned long long)));
@@ -486,6 +503,7 @@ struct Run {
 	rt_scene* sc; rt_scene::Lane* ln; hipStream_t st; Source src; int maxDepth; uint32_t seed; uint32_t flags; uint32_t aaSq;
 	rt_stats stats{};
 	RtPick pick{ nullptr, nullptr, 0 };   // rt_trace_pick: where the narration's events go
+	uint32_t texRecords = 0;               // RtTexFix records the current batch has left so far
 
 	// Which traversal form a level uses.  Level 0 of a frame (and its shadow rays) is coherent by construction: 64
 	// consecutive queue slots are an 8x8 pixel block.  Deeper levels and caller-supplied rays are walked per lane.
@@ -508,13 +526,14 @@ struct Run {
 		uint32_t n = cnt;
 		bool shadowPending = false;
 		uint64_t nearRays = 0, shadowRays = 0, nLevels = 0;
+		texRecords = 0;
 		for (int level = 0; level <= maxDepth && n > 0; level++) {
 			HIPCHK(hipMemsetAsync(ln->ctr, 0, RT_COUNTER_RESET_BYTES, st));   // queue counts and work cursors
 			if (timeK) HIPCHK(hipEventRecord(ln->ev[2], st));
 			rtk_intersect(st, sc->dev, sc->hasCsg, count, coherent(level), coherent(level) ? sc->maxBlocksPacketNear : sc->maxBlocks, ln->ray[cur], n, ln->hitq, ln->ctr);
 			if (timeK) HIPCHK(hipEventRecord(ln->ev[3], st));
 			rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, n, ln->ray[cur ^ 1], ln->surfq, ln->transq, ln->ctr, sc->accum, aaSq, maxDepth,
-			          sc->shadowRaysPerSurface > 0, level == 0 ? src.outHit : nullptr, src.outId, src.outT, pick);
+			          sc->shadowRaysPerSurface > 0, level == 0 ? src.outHit : nullptr, src.outId, src.outT, pick, sc->texFix(*ln));
 			if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, n, ln->ray[cur ^ 1], ln->ctr, sc->accum, aaSq, maxDepth, pick);
 			// Level 0 of a frame lit by point-type lights only: the shadow packets are queued before the host has seen the
 			// counts (the kernels read them on the device), and the host waits for the count read-back while they run --
@@ -533,6 +552,7 @@ struct Run {
 				HIPCHK(hipEventElapsedTime(&ms, ln->ev[2], ln->ev[3])); stats.nearest_ms += ms;
 				if (shadowPending) { HIPCHK(hipEventElapsedTime(&ms, ln->ev[4], ln->ev[5])); stats.shadow_ms += ms; shadowPending = false; }
 			}
+			texRecords = ln->ctrHost->texrec_count;
 			if (ln->ctrHost->overflow) return 1;
 			nLevels++;
 			// inactive slots of a partial edge tile are not rays
@@ -554,6 +574,8 @@ struct Run {
 			HIPCHK(hipEventSynchronize(ln->ev[5]));
 			HIPCHK(hipEventElapsedTime(&ms, ln->ev[4], ln->ev[5])); stats.shadow_ms += ms;
 		}
+		// hits on reflective textured triangles that their own reflected ray's subtree came back to: lit with the last hit's texel
+		rtk_texel_fix(st, sc->dev, sc->hasCsg, sc->texFix(*ln), texRecords, ln->ctr, sc->accum, aaSq, seed, true);
 		stats.rays_nearest += nearRays; stats.rays_shadow += shadowRays; stats.levels = std::max<uint64_t>(stats.levels, nLevels);
 		return RT_OK;
 	}
@@ -566,6 +588,7 @@ struct Run {
 		stats = saved;
 		stats.batch_splits++;
 		HIPCHK(hipMemsetAsync(&ln->ctr->overflow, 0, sizeof(uint32_t), st));
+		rtk_texel_fix(st, sc->dev, sc->hasCsg, sc->texFix(*ln), texRecords, ln->ctr, sc->accum, aaSq, seed, false);   // drop the discarded batch's records
 		// clear this batch's pixels (resolve with no destination only zeroes the accumulators)
 		rtk_resolve(st, sc->accum, src.W, src.H, src.tileRank, src.tileRanks, r0 / aaSq, cnt / aaSq, aaSq, src.camera ? 0 : 1, nullptr);
 		if (cnt <= aaSq) { rt::set_error("ray queue too small for the ray tree of a single pixel (raise RT_QUEUE_RAYS)"); return RT_ELIMIT; }
@@ -816,6 +839,11 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 		if (kt[0] != 0 || kt[1] != 0 || kt[2] != 0) sc->hasTransmissive = true;
 	}
 
+	for (int64_t i = 0; i < s->n_tris && !sc->texelFix; i++) {
+		const float* kr = s->materials[s->tris[i].mat].reflective;
+		if (s->tris[i].uv >= 0 && (kr[0] != 0 || kr[1] != 0 || kr[2] != 0) && getenv("RT_NO_TEXEL_FIX") == nullptr) sc->texelFix = true;
+	}
+
 	std::vector<int32_t> pl;
 	for (int i = 0; i < s->n_lights; i++) {
 		const rt_light& L = s->lights[i];
@@ -828,6 +856,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	sc->pointLights = const_cast<int32_t*>(plDev);
 
 	sc->qcap = std::max<uint32_t>(1024, envU32("RT_QUEUE_RAYS", 8u << 20));
+	sc->texCap = std::min<uint32_t>(sc->qcap, 2u << 20);
 	const int nLanes = (int)std::min<uint32_t>(RT_MAX_LANES, std::max<uint32_t>(1, envU32("RT_LANES", 4)));   // the box exposes 4 hardware queues per process
 	sc->lanes.resize(nLanes);
 	// lane 0 runs on the caller's stream (renderShard); creating a stream it would not use would still claim one of
@@ -858,6 +887,7 @@ void rt_scene_free(rt_scene* sc) {
 	for (void* p : sc->allocs) (void)hipFree(p);
 	if (sc->accum.rgb) (void)hipFree(sc->accum.rgb);
 	if (sc->accum.nonfinite) (void)hipFree(sc->accum.nonfinite);
+	if (sc->texHeads) (void)hipFree(sc->texHeads);
 	for (auto& ln : sc->lanes) {
 		if (ln.ctrHost) (void)hipHostFree(ln.ctrHost);
 		for (auto& ev : ln.ev) if (ev) (void)hipEventDestroy(ev);

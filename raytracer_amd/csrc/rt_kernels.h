@@ -84,6 +84,8 @@ struct RtCounters {
 	uint32_t reserved[2];     // ---- everything above is reset at the start of every level (RT_COUNTER_RESET_BYTES) ----
 	uint32_t overflow;        // an append found its queue full (the batch is re-run in halves)
 	uint32_t pad;
+	uint32_t texrec_count;    // RtTexFix records appended by k_shade since k_texel_reset (all levels of a batch)
+	uint32_t pad2;
 	unsigned long long nodes_nearest, prims_nearest;   // RT_FLAG_COUNTERS: 64 B nodes read / primitive tests in k_intersect
 	unsigned long long nodes_shadow, prims_shadow;     // ... and in the shadow kernels
 #if RT_PROF
@@ -92,6 +94,15 @@ struct RtCounters {
 	uint32_t waveLog[2][8192][8];                      // per wave: start, end (100 MHz wall clock), longest packet, packets; that packet's union steps, max / sum of per-ray nodes, rays
 #endif
 };
+
+// Texel state of textured triangles (texturemesh.cpp:49-50, objects.cpp:62-79): TextureTriangle::lightPoint writes the texel into the
+// triangle's own material and Object::lightPoint reads it back only after it has traced the reflected ray, so a hit whose reflection
+// subtree comes back to the same triangle is lit with the texel of the LAST hit on it.  A level is shaded before the levels below it
+// exist, so every hit on a reflective textured triangle leaves a record here, chained per pixel; when a batch's levels are through,
+// k_texel_fix finds the records whose subtree holds a later hit on the same triangle and adds the difference of the ambient and
+// diffuse terms (shadow rays re-traced: such hits are rare).  Scenes without reflective textured triangles carry none of it.
+struct RtTexRec { uint32_t pixKey, path, tri, next; float c[3], wl[3], p[3], N[3]; };   // 64 B
+struct RtTexFix { RtTexRec* rec; uint32_t* heads; uint32_t cap; };                      // rec == nullptr: off.  heads: one list per pixel, kInactive = empty
 
 // 32.32 fixed-point accumulators: three planes of npix, plus a per-pixel "saw a NaN/inf" byte
 struct RtAccum { unsigned long long* rgb; uint8_t* nonfinite; uint32_t npix; };
@@ -107,7 +118,10 @@ struct RtPick { rt_pick_event* ev; uint32_t* count; uint32_t cap; };
 void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint32_t maxRequests, RtQueue nq, RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth,
                   RtPick pick = RtPick{ nullptr, nullptr, 0 });
 void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
-               uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick = RtPick{ nullptr, nullptr, 0 });
+               uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick = RtPick{ nullptr, nullptr, 0 },
+               RtTexFix tex = RtTexFix{ nullptr, nullptr, 0 });
+// after the last level of a batch: the corrections for `count` records, then the lists and the record counter are emptied again
+void rtk_texel_fix(hipStream_t st, const DevScene& S, bool csg, RtTexFix tex, uint32_t count, RtCounters* ctr, RtAccum A, uint32_t aaSq, uint32_t seed, bool apply);
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                       RtAccum A, uint32_t aaSq, RtCounters* ctr, bool countOnDevice = false, int maxBlocksPairs = 0);
 void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t samples, uint32_t seed,

@@ -22,6 +22,8 @@
 //   k_shadow_point_packet,  packets with two lights per surface (two rays per lane), with one, and the per-lane form
 //   k_shadow_point
 //   k_shadow_area           AreaLight::lightPoint arealight.cpp:7-22, one lane per sample, segmented wave reduction
+//   k_texel_fix             the material state TextureTriangle::lightPoint leaves behind (texturemesh.cpp:49-50): hits on reflective
+//                           textured triangles that their own reflection subtree comes back to, corrected after the last level
 //   k_resolve               fixed point -> float RGB (+ the /4 of q1.cpp:140 for supersampling)
 #include "rt_kernels.h"
 #include "rt_device.h"
@@ -1065,10 +1067,10 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 // ---------------------------------------------------------------------------------------------------------
 // shade: everything Object::lightPoint does except the shadow rays
 // ---------------------------------------------------------------------------------------------------------
-template <bool CSG, bool PICK>
+template <bool CSG, bool PICK, bool TEXFIX>
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
                                                   RtAccum A, uint32_t aaSq, int maxDepth, int wantSurfaces,
-                                                  uint8_t* outHit, int32_t* outId, float* outT, RtPick pick) {
+                                                  uint8_t* outHit, int32_t* outId, float* outT, RtPick pick, RtTexFix tex) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	// every record is read at once (index clamped, result masked): one memory round trip instead of two
 	const uint32_t ic = i < n ? i : 0u;
@@ -1091,6 +1093,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 	if (PICK && live && !hit && path > 1u) pickEmit(pick, path, RT_PICK_MISS, 0, 0, mk3(0, 0, 0));
 
 	bool wantR = false, wantX = false, wantS = false;
+	bool wantTex = false;      // TEXFIX: a hit on a reflective textured triangle leaves a record (RtTexFix)
+	uint32_t texTri = 0;
 	float refraction = 0;
 	f3 p = mk3(0, 0, 0), N = mk3(0, 0, 0), V = mk3(0, 0, 0);
 	f3 rO = p, rD = p, rW = p, tW = p, wl = p;
@@ -1123,6 +1127,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 				const int height = S.textures[tex].height, width = S.textures[tex].width;
 				const uint8_t* px = texel(S, tex, f2i(u * width), f2i(v * height));   // texturemesh.cpp:7-16
 				ka[0] = kd[0] = float(px[0]) / 255; ka[1] = kd[1] = float(px[1]) / 255; ka[2] = kd[2] = float(px[2]) / 255;
+				if (TEXFIX && !isZero3(m.reflective)) { wantTex = true; texTri = ix; }
 			}
 		} else if (type == RT_PRIM_BOX) boxNormal(S.boxes[ix].b, p, N);
 		else if (CSG) N = csgNormal(S, S.csgs[ix], e, d, qu(hq, HQ_TAG, i));
@@ -1201,6 +1206,21 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueu
 			qsf(tq, TQ_WR, st, tW.x); qsf(tq, TQ_WG, st, tW.y); qsf(tq, TQ_WB, st, tW.z);
 			qsu(tq, TQ_PIX, st, pixKey); qsu(tq, TQ_PATH, st, path);
 		} else ctr->overflow = 1;
+	}
+	if (TEXFIX) {
+		const uint32_t slot = wavePush(wantTex, &ctr->texrec_count);
+		if (wantTex) {
+			if (slot < tex.cap) {
+				RtTexRec r;
+				r.pixKey = pixKey; r.path = path; r.tri = texTri;
+				r.c[0] = kd[0]; r.c[1] = kd[1]; r.c[2] = kd[2];
+				r.wl[0] = wl.x; r.wl[1] = wl.y; r.wl[2] = wl.z;
+				r.p[0] = p.x; r.p[1] = p.y; r.p[2] = p.z;
+				r.N[0] = N.x; r.N[1] = N.y; r.N[2] = N.z;
+				r.next = atomicExch(&tex.heads[pixel], slot);
+				tex.rec[slot] = r;
+			} else ctr->overflow = 1;
+		}
 	}
 	if (wantS) {
 		if (ss < sq.cap) {
@@ -1538,6 +1558,102 @@ __global__ __launch_bounds__(kBlock) void k_shadow_query(DevScene S, const float
 	if (shadowOut) { shadowOut[3 * (size_t)i] = T.shadow.x; shadowOut[3 * (size_t)i + 1] = T.shadow.y; shadowOut[3 * (size_t)i + 2] = T.shadow.z; }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// texel state of re-hit textured triangles (RtTexFix, rt_kernels.h)
+// ---------------------------------------------------------------------------------------------------------
+// position of two rays of one ray tree in the order the reference executes them (depth first: a hit, its reflected ray's subtree,
+// its transmitted ray's subtree): path 1 = the first ray, 2p = the reflection of p, 2p + 1 = its transmission
+__device__ __forceinline__ bool pathBefore(uint32_t a, uint32_t b) {
+	const int da = 31 - __clz((int)a), db = 31 - __clz((int)b);
+	if (da > db) { const uint32_t up = a >> (da - db); return up != b && up < b; }   // b is an ancestor of a: b first
+	const uint32_t up = b >> (db - da);
+	if (up == a) return da != db;                                                     // a is an ancestor of b: a first
+	return a < up;
+}
+// is ray q inside the subtree of the REFLECTED ray of the hit of ray p?
+__device__ __forceinline__ bool inReflectionSubtree(uint32_t p, uint32_t q) {
+	const int dp = 31 - __clz((int)p), dq = 31 - __clz((int)q);
+	return dq > dp && (q >> (dq - dp - 1)) == 2u * p;
+}
+
+// One record per lane.  The lights are walked as Object::lightPoint walks them (objects.cpp:77-79), with the material the reference
+// would have used (the texel of the last hit on the triangle inside the reflected ray's subtree) and with the material the shading
+// kernel did use (the hit's own texel); the pixel gets the difference of the ambient and diffuse terms.  Shadow rays are those the
+// shadow kernels traced (same origin, same targets, same samples of the area lights): they are not counted again.
+template <bool CSG>
+__global__ __launch_bounds__(kBlock) void k_texel_fix(DevScene S, RtTexFix tex, uint32_t count, RtAccum A, uint32_t aaSq, uint32_t seed) {
+	__shared__ int32_t stack[kStack][kBlock];
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= count) return;
+	const RtTexRec r = tex.rec[i];
+	uint32_t best = kInactive, bestPath = 0;
+	for (uint32_t j = tex.heads[r.pixKey / aaSq]; j != kInactive; j = tex.rec[j].next) {
+		if (j == i) continue;
+		const uint32_t q = tex.rec[j].path;
+		if (tex.rec[j].pixKey != r.pixKey || tex.rec[j].tri != r.tri || !inReflectionSubtree(r.path, q)) continue;
+		if (best == kInactive || pathBefore(bestPath, q)) { best = j; bestPath = q; }
+	}
+	if (best == kInactive) return;
+	const float* c1 = tex.rec[best].c;
+	if (c1[0] == r.c[0] && c1[1] == r.c[1] && c1[2] == r.c[2]) return;
+	const f3 kNew = ld3(c1), kOld = ld3(r.c), p = ld3(r.p), N = ld3(r.N), wl = ld3(r.wl);
+	auto diffuse = [](f3 I, f3 kd, float NL) {   // addDiffuse, raymath.cpp:34-42
+		f3 dcol = I * kd * NL;
+		if (dcol.x < 0) dcol.x = 0;
+		if (dcol.y < 0) dcol.y = 0;
+		if (dcol.z < 0) dcol.z = 0;
+		return dcol;
+	};
+	f3 sumNew = mk3(0, 0, 0), sumOld = mk3(0, 0, 0);
+	for (int l = 0; l < S.n_lights; l++) {
+		const rt_light L = S.lights[l];
+		if (L.type == RT_LIGHT_AMBIENT) { sumNew = sumNew + ld3(L.colour) * kNew; sumOld = sumOld + ld3(L.colour) * kOld; continue; }
+		const bool area = L.type == RT_LIGHT_RECT || L.type == RT_LIGHT_CIRC;
+		const uint32_t ns = area ? (uint32_t)L.samples : 1u;
+		f3 totNew = mk3(0, 0, 0), totOld = mk3(0, 0, 0);
+		for (uint32_t smp = 0; smp < ns; smp++) {
+			f3 Ld, lightPos;
+			if (!area) pointLightGeometry(L, p, Ld, lightPos);
+			else {
+				float r1, r2;
+				rng2(seed, r.pixKey, r.path, (uint32_t)l, smp, r1, r2);
+				float xDisplacement, yDisplacement;
+				if (L.type == RT_LIGHT_RECT) {   // arealight.cpp:37-42
+					xDisplacement = (float)(((double)r1 - 0.5) * (double)L.width);
+					yDisplacement = (float)(((double)r2 - 0.5) * (double)L.height);
+				} else {   // arealight.cpp:79-87
+					const float angle = (float)((double)(r1 * 2) * RTD_PI);
+					const float displacement = L.radius * sqrtf(r2);
+					xDisplacement = displacement * cosf(angle);
+					yDisplacement = displacement * sinf(angle);
+				}
+				lightPos = ld3(L.position) + ld3(L.planeX) * xDisplacement + ld3(L.planeY) * yDisplacement;
+				Ld = normalize(lightPos - p);
+			}
+			Trav T;
+			travInit<true>(S, T, p, lightPos - p);
+			while (T.cur != kEmpty) travRound<true, CSG, false>(S, stack, T);
+			if (!T.lit) continue;
+			if (L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff)) continue;   // objects.cpp:451
+			const f3 I = ld3(L.colour) * T.shadow;
+			const float NL = dot(N, Ld);
+			totNew = totNew + diffuse(I, kNew, NL);
+			totOld = totOld + diffuse(I, kOld, NL);
+		}
+		if (area) { totNew = totNew / (float)ns; totOld = totOld / (float)ns; }   // arealight.cpp:21
+		sumNew = sumNew + totNew; sumOld = sumOld + totOld;
+	}
+	accumAdd(A, r.pixKey / aaSq, wl * sumNew);
+	accumAdd(A, r.pixKey / aaSq, -(wl * sumOld));
+}
+
+// empties the lists the records hang in and the record counter: the next batch starts clean
+__global__ __launch_bounds__(kBlock) void k_texel_reset(RtTexFix tex, uint32_t count, RtCounters* ctr, uint32_t aaSq) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i == 0) ctr->texrec_count = 0;
+	if (i < count) tex.heads[tex.rec[i].pixKey / aaSq] = kInactive;
+}
+
 // fixed point -> float RGB for the pixels of local range [lp0, lp0+count); clears the accumulators for the next frame
 __global__ __launch_bounds__(kBlock) void k_resolve(RtAccum A, int W, int H, int tileRank, int tileRanks, uint32_t lp0, uint32_t count, uint32_t aaSq,
                                                     int linear, float* rgb) {
@@ -1640,14 +1756,28 @@ void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, 
 	RT_LAUNCH(k_export_hits, n, st, S, hq, n, hit, id, t);
 }
 void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
-               uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick) {
+               uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick, RtTexFix tex) {
 	if (pick.ev) {   // rt_trace_pick: the variants that narrate
-		if (csg) RT_LAUNCH((k_shade<true, true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick);
-		else RT_LAUNCH((k_shade<false, true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick);
+		if (csg) RT_LAUNCH((k_shade<true, true, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+		else RT_LAUNCH((k_shade<false, true, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
 		return;
 	}
-	if (csg) RT_LAUNCH((k_shade<true, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick);
-	else RT_LAUNCH((k_shade<false, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick);
+	if (tex.rec) {   // scenes with reflective textured triangles
+		if (csg) RT_LAUNCH((k_shade<true, false, true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+		else RT_LAUNCH((k_shade<false, false, true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+		return;
+	}
+	if (csg) RT_LAUNCH((k_shade<true, false, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+	else RT_LAUNCH((k_shade<false, false, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+}
+void rtk_texel_fix(hipStream_t st, const DevScene& S, bool csg, RtTexFix tex, uint32_t count, RtCounters* ctr, RtAccum A, uint32_t aaSq, uint32_t seed, bool apply) {
+	if (!tex.rec || count == 0) return;
+	count = count < tex.cap ? count : tex.cap;
+	if (apply) {
+		if (csg) RT_LAUNCH((k_texel_fix<true>), count, st, S, tex, count, A, aaSq, seed);
+		else RT_LAUNCH((k_texel_fix<false>), count, st, S, tex, count, A, aaSq, seed);
+	}
+	RT_LAUNCH(k_texel_reset, count, st, tex, count, ctr, aaSq);
 }
 void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint32_t maxRequests, RtQueue nq, RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth, RtPick pick) {
 	if (maxRequests == 0) return;

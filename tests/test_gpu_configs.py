@@ -153,16 +153,16 @@ def test_random_mixed_scenes(tmp_path, seed):
     s = primary_targets_np(cam, W, H)
     e = np.tile(np.array(cam.c.eye[:], np.float32), (W * H, 1))
     r = sc.trace_batch(e, s, max_depth=6, seed=7)
-    # Known gap: a reflective textured triangle that its own reflected ray's subtree comes back to is lit by
-    # the reference with the texel of the LAST hit on it (texturemesh.cpp:49-50 writes the triangle's material, objects.cpp:77-79
-    # reads it after the recursion).  The oracle reproduces that; the device lights every hit with its own texel.  So: the device
-    # equals the own-texel oracle everywhere, and the pixels where the two oracles differ are counted and few.
-    exact = oracle.trace_batch(flat, e, s, max_depth=6, seed=7, threads=8)
+    # A reflective textured triangle that its own reflected ray's subtree comes back to is lit by the reference with the texel of the
+    # LAST hit on it (texturemesh.cpp:49-50 writes the triangle's material, objects.cpp:77-79 reads it after the recursion).  The
+    # oracle reproduces that, and so does the device (k_texel_fix); the oracle with that state switched off shows how many pixels
+    # of the scene it concerns.
+    o = oracle.trace_batch(flat, e, s, max_depth=6, seed=7, threads=8)
     with oracle.own_texels():
-        o = oracle.trace_batch(flat, e, s, max_depth=6, seed=7, threads=8)
-    assert np.array_equal(exact["id"], o["id"]) and np.array_equal(bits(exact["t"]), bits(o["t"])) and exact["rays_shadow"] == o["rays_shadow"]
-    state8 = np.abs(rgb8(exact["rgb"]).astype(int) - rgb8(o["rgb"]).astype(int)).max(axis=1)
-    assert (state8 > 1).mean() < 2e-3, f"{(state8 > 1).sum()} pixels depend on the reference's texel state"
+        own = oracle.trace_batch(flat, e, s, max_depth=6, seed=7, threads=8)
+    state = np.abs(own["rgb"] - o["rgb"]).max(axis=1) > 1e-4
+    print(f"seed {seed}: {int(state.sum())} pixels depend on the texel state")
+    assert np.abs(r["rgb"][state] - o["rgb"][state]).max(initial=0) < 2e-3
     assert np.array_equal(r["id"], o["id"]) and np.array_equal(bits(r["t"]), bits(o["t"]))
     assert sc.last_stats["rays_nearest"] == o["rays_nearest"] and sc.last_stats["rays_shadow"] == o["rays_shadow"]
     d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(o["rgb"]).astype(int)).max(axis=1)
@@ -305,3 +305,46 @@ def test_light_pairs_and_single_light_packets_agree(tmp_path, monkeypatch):
         assert st["rays_nearest"] == nn and st["rays_shadow"] == ns
         assert (np.abs(rgb8(paired).astype(int) - rgb8(ref).astype(int)).max(axis=2) > 1).mean() < 1e-3
         sc.close()
+
+
+@pytest.mark.parametrize("queue_rays", [None, 32768])
+def test_texel_state_with_many_records(tmp_path, monkeypatch, queue_rays):
+    """A reflective textured terrain under a mirror: nearly every ray tree comes back to a textured triangle it has hit before, so
+    tens of thousands of hits are lit with a later hit's texel (texturemesh.cpp:49-50 / objects.cpp:62-79; k_texel_fix).  On a frame
+    cut into four shards, and with ray queues (and with them the record buffer) so small that batches overflow and are re-run."""
+    import json
+    from raytracer_amd.scenes import _mesh_json, height_field, tiles_texture, write_bmp24
+    write_bmp24(str(tmp_path / "t.bmp"), tiles_texture(64, 8))
+    tris, uvs = height_field(6, seed=3, x0=-6.0, x1=6.0, z0=-14.0, z1=-1.0)   # large triangles: rays come back to the same one
+    mesh = {"type": "texturemesh", "texture": "t.bmp", "material": {"specular": [0.3, 0.3, 0.3], "shininess": 10.0, "reflective": [0.5, 0.4, 0.6]}}
+    mesh.update(_mesh_json(tris, uvs))
+    scene = {"camera": {"field": 60, "background": [0.1, 0.1, 0.2]},
+             "objects": [mesh, {"type": "box", "point1": [-8, 1.5, -16], "point2": [8, 2.0, 1], "material": {"diffuse": [0.1, 0.1, 0.1], "reflective": [0.8, 0.8, 0.8]}},
+                         {"type": "sphere", "position": [0.5, 0.2, -6], "radius": 0.7, "material": {"diffuse": [0.5, 0.2, 0.2], "transmissive": [0.6, 0.6, 0.6], "refraction": 1.3}}],
+             "lights": [{"type": "ambient", "color": [0.3, 0.3, 0.3]}, {"type": "point", "color": [0.8, 0.8, 0.7], "position": [0, 1.2, -5]},
+                        {"type": "directional", "color": [0.3, 0.3, 0.4], "direction": [0.2, -1, -0.3]},
+                        {"type": "rectangular", "color": [0.4, 0.4, 0.3], "position": [1.0, 1.4, -7.0], "normal": [0, -1, 0], "orientation": [1, 0, 0],
+                         "width": 1.0, "height": 0.6, "samples": 3}]}
+    path = tmp_path / "mirror_terrain.json"
+    path.write_text(json.dumps(scene))
+    flat = rt.FlatScene.from_json(str(path))
+    if queue_rays:
+        monkeypatch.setenv("RT_QUEUE_RAYS", str(queue_rays))
+    sc = rt.Scene(flat, 0)
+    W, H, depth = 640, 360, 5
+    cam = rt.Camera(flat.fov, W, H, eye=(0, 1.0, -7.0), rot_x=-1.3)   # between the two, looking down: the bounces stay on one triangle
+    img = sc.render(W, H, camera=cam, max_depth=depth, seed=9)
+    splits = sc.last_stats["batch_splits"]
+    nn, ns = sc.last_stats["rays_nearest"], sc.last_stats["rays_shadow"]
+    sc.close()
+    oracle.texel_cases()
+    ref, onn, ons = oracle.render(flat, cam, W, H, max_depth=depth, seed=9, threads=8)
+    cases = oracle.texel_cases()
+    with oracle.own_texels():
+        own, _, _ = oracle.render(flat, cam, W, H, max_depth=depth, seed=9, threads=8)
+    state = np.abs(own - ref).max(axis=2) > 1e-3
+    print(f"{cases} hits lit with a later hit's texel, {int(state.sum())} of {W * H} pixels visibly; {splits} batch splits")
+    assert cases > 10000 and state.sum() > 5000
+    assert (nn, ns) == (onn, ons)
+    assert np.abs(img - ref).max() < 2e-4
+    assert bool(splits) == bool(queue_rays)

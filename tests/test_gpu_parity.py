@@ -55,9 +55,9 @@ def test_secondary_and_shadow_batches_vs_reference_dump(name, gpu_scenes, golden
 
 @pytest.mark.parametrize("name", list(SCENES_RANDOM))
 def test_random_scene_vs_reference_dump(name, gpu_scenes, flat_scenes, golden):
-    """The compiled reference on a random scene holding every primitive, material and light kind.  Ids, t and ray counts as on the
-    bundled scenes; RGB within 1/255 except where the reference lights a re-hit textured triangle with a later hit's texel (known
-    gap): those pixels -- found by switching that state off in the oracle -- equal the own-texel oracle."""
+    """The compiled reference on a random scene holding every primitive, material and light kind.  Ids, t, ray counts and RGB as on
+    the bundled scenes.  random_5 has two pixels where the reference lights a textured triangle with the texel of a LATER hit on it
+    (texturemesh.cpp:49-50 / objects.cpp:62-79, k_texel_fix on the device): the oracle with that state switched off shows which."""
     g = golden(name)
     n = int(g["W"]) * int(g["H"])
     e = np.zeros((n, 3), np.float32)
@@ -65,13 +65,17 @@ def test_random_scene_vs_reference_dump(name, gpu_scenes, flat_scenes, golden):
     r = sc.trace_batch(e, g["s"])
     assert np.array_equal(r["hit"], g["hit"]) and np.array_equal(r["id"], g["id"]) and np.array_equal(bits(r["t"]), bits(g["t"]))
     assert sc.last_stats["rays_nearest"] == int(g["rays_nearest"]) and sc.last_stats["rays_shadow"] == int(g["rays_shadow"])
+    d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(g["rgb"]).astype(int)).max(axis=1)
+    assert d8.max() <= 1
+    assert np.nanmax(np.abs(r["rgb"] - g["rgb"])) < 2e-3
     with oracle.own_texels():
         own = oracle.trace_batch(flat_scenes(name), e, g["s"], seed=1, threads=4)
-    state = (bits(own["rgb"]) != bits(g["rgb"])).any(axis=1)
+    state = np.abs(own["rgb"] - g["rgb"]).max(axis=1) > 1e-4
     assert state.sum() == {"random_5": 2, "random_8": 0}[name]
-    d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(g["rgb"]).astype(int)).max(axis=1)
-    assert d8[~state].max() <= 1
-    assert np.abs(rgb8(r["rgb"]).astype(int) - rgb8(own["rgb"]).astype(int)).max() <= 1
+    assert np.abs(r["rgb"][state] - g["rgb"][state]).max(initial=0) < 1e-5      # ... and the device follows the reference there
+    # the frame path (lanes, shards) gives the same pixels
+    img = sc.render(int(g["W"]), int(g["H"]))
+    assert np.abs(img.reshape(-1, 3) - r["rgb"]).max() < 1e-6
 
 
 def test_scene_m_same_samples_as_oracle(gpu_scenes, flat_scenes, golden):

@@ -1758,7 +1758,10 @@ void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, 
 void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
                uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick, RtTexFix tex) {
 	if (pick.ev) {   // rt_trace_pick: the variants that narrate
-		if (csg) RT_LAUNCH((k_shade<true, true, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+		if (tex.rec) {
+			if (csg) RT_LAUNCH((k_shade<true, true, true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+			else RT_LAUNCH((k_shade<false, true, true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+		} else if (csg) RT_LAUNCH((k_shade<true, true, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
 		else RT_LAUNCH((k_shade<false, true, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
 		return;
 	}

@@ -73,9 +73,12 @@ def test_random_scene_vs_reference_dump(name, gpu_scenes, flat_scenes, golden):
     state = np.abs(own["rgb"] - g["rgb"]).max(axis=1) > 1e-4
     assert state.sum() == {"random_5": 2, "random_8": 0}[name]
     assert np.abs(r["rgb"][state] - g["rgb"][state]).max(initial=0) < 1e-5      # ... and the device follows the reference there
-    # the frame path (lanes, shards) gives the same pixels
+    # the frame path (lanes, shards) gives the same pixels, and so does the picked ray (trace(..., pick = true))
     img = sc.render(int(g["W"]), int(g["H"]))
     assert np.abs(img.reshape(-1, 3) - r["rgb"]).max() < 1e-6
+    for i in np.where(state)[0]:
+        hit, rgb, text = sc.trace_pick(e[i], g["s"][i])
+        assert hit and np.abs(np.asarray(rgb) - g["rgb"][i]).max() < 1e-5 and text.count("object triangle hit at") >= 3
 
 
 def test_scene_m_same_samples_as_oracle(gpu_scenes, flat_scenes, golden):

@@ -196,7 +196,7 @@ def test_odd_frame_shapes(W, H, aa, gpu_scenes, flat_scenes):
     assert np.array_equal(bits(full.cpu().numpy()), bits(img))
 
 
-@pytest.mark.parametrize("name", ["a", "b", "e", "g", "h", "k"])
+@pytest.mark.parametrize("name", ["a", "b", "e", "g", "h", "k", "random_5", "random_8"])
 def test_pick_narration_vs_reference(name, gpu_scenes, flat_scenes):
     """trace(e, s, colour, pick=true): what the compiled reference prints on std::cout for 64 pixels of a 160x120 frame
     (tests/golden/pick_<scene>.txt, tools/make_pick_golden.py) -- hits, reflections, interior reflections of the exit search,

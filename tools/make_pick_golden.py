@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tests/golden/pick_<scene>.txt: the compiled reference's own narration of trace(..., pick = true) for a grid of pixels
 (oracle/_ref/ref_driver ... pick, built by `make -C oracle ref`; runs only in the build container, where /root/reference is)."""
-import os, subprocess, sys
+import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
 REF_SRC = "/root/reference/src"
@@ -10,9 +10,16 @@ PIXELS = [(x, y) for y in range(7, H, 15) for x in range(9, W, 19)]
 
 
 def main():
-    for scene in sys.argv[1:] or ["a", "b", "e", "g", "h", "k"]:
+    for scene in sys.argv[1:] or ["a", "b", "e", "g", "h", "k", "random_5", "random_8"]:
         args = [DRIVER, scene, str(W), str(H), "pick"] + [str(v) for p in PIXELS for v in p]
-        out = subprocess.run(args, cwd=REF_SRC, check=True, capture_output=True, text=True).stdout
+        if scene.startswith("random_"):   # a generated scene (raytracer_amd.scenes.random_scene): the reference loads it from a scratch directory
+            sys.path.insert(0, ROOT)
+            from raytracer_amd import scenes
+            with tempfile.TemporaryDirectory() as tmp:
+                scenes.random_scene(os.path.join(tmp, "scenes"), seed=int(scene[7:]), n_objects=40)
+                out = subprocess.run(args, cwd=tmp, check=True, capture_output=True, text=True).stdout
+        else:
+            out = subprocess.run(args, cwd=REF_SRC, check=True, capture_output=True, text=True).stdout
         out = out[out.index("== pixel"):]
         with open(os.path.join(ROOT, "tests", "golden", f"pick_{scene}.txt"), "w") as f:
             f.write(out)

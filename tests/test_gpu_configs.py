@@ -1,5 +1,5 @@
-"""GPU suite, part 2: the BASELINE.json configurations at their real sizes.  No reference dump exists for these (the
-reference cannot run here and the oracle is too slow for whole 1080p frames), so they are pinned by
+"""GPU suite, part 2: the BASELINE.json configurations at their real sizes.  The full-size C2 scene has a dump of the compiled
+reference at 256x144 (tests/golden/ref_c2_224.npz); whole 1080p frames are beyond the reference and the oracle, so they are pinned by
   * the oracle on sampled rays of the full-size frame (ids exact, t bit-exact, 8-bit RGB),
   * size-independent properties: the frame is bit-identical run to run, any tile sharding composes to the same frame, and
     the two traversal forms (packets for camera rays, per-lane walks for caller-supplied rays) give bit-identical images,
@@ -47,6 +47,33 @@ def test_numpy_primary_targets_equal_oracle(c2):
     flat, _ = c2
     cam = rt.Camera(flat.fov, 96, 54, eye=(0, 1.5, 1.0), rot_x=-0.3)
     assert np.array_equal(bits(primary_targets_np(cam, 96, 54)), bits(oracle.primary_targets(cam, 96, 54)))
+
+
+def test_c2_full_size_vs_compiled_reference(c2):
+    """The benchmark's own scene -- all 100 352 triangles, generated again here by the same deterministic generator -- against what
+    the COMPILED REFERENCE computed for it at 256x144 from bench.py's camera (tools/make_random_golden.py c2_224): ids, t and ray
+    counts exact, RGB within 1/255 (texel-boundary pixels on the bump-mapped spheres counted, as below)."""
+    import os
+    from conftest import GOLD
+    flat, sc = c2
+    g = dict(np.load(os.path.join(GOLD, "ref_c2_224.npz")))
+    n = int(g["W"]) * int(g["H"])
+    e = np.tile(g["eye"].astype(np.float32), (n, 1))
+    r = sc.trace_batch(e, g["s"])
+    assert np.array_equal(r["hit"], g["hit"]) and np.array_equal(r["id"], g["id"]) and np.array_equal(bits(r["t"]), bits(g["t"]))
+    assert sc.last_stats["rays_nearest"] == int(g["rays_nearest"]) and sc.last_stats["rays_shadow"] == int(g["rays_shadow"])
+    d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(g["rgb"]).astype(int)).max(axis=1)
+    print(f"{int((d8 > 1).sum())} of {n} pixels beyond 1/255")
+    assert (d8 > 1).mean() < 2e-3
+    on_mesh = g["id"] < flat.info.n_objects - 2          # the two spheres were loaded last
+    assert d8[on_mesh & (g["hit"] != 0)].max() <= 1
+    a = sc.shadow_batch(g["shd_p"], g["shd_l"])
+    assert np.array_equal(a["lit"], g["shd_lit"].astype(np.uint8))
+    # the frame path (packets, lanes) on the same camera
+    cam = rt.Camera(flat.fov, int(g["W"]), int(g["H"]), eye=tuple(float(v) for v in g["eye"]), rot_x=-0.3)
+    assert np.array_equal(bits(primary_targets_np(cam, int(g["W"]), int(g["H"]))), bits(g["s"]))
+    img = sc.render(int(g["W"]), int(g["H"]), camera=cam)
+    assert np.array_equal(bits(img.reshape(-1, 3)), bits(r["rgb"]))
 
 
 def test_c2_1080p_sampled_rays_vs_oracle(c2):
@@ -98,6 +125,29 @@ def test_c2_ray_counts_vs_oracle_reduced_frame(c2):
     assert sc.last_stats["rays_nearest"] == nn and sc.last_stats["rays_shadow"] == ns
     d8 = np.abs(rgb8(img).astype(int) - rgb8(ref).astype(int)).max(axis=2)
     assert (d8 > 1).mean() < 2e-3
+
+
+def test_c3_vs_compiled_reference(tmp_path):
+    """BASELINE config 3 against what the COMPILED REFERENCE computed for it at 240x135 (tests/golden/ref_c3.npz, the reference's own
+    depth limit of 16): ids, t, ray counts exact, RGB within 1/255; sampled secondary rays and shadow queries."""
+    import os
+    from conftest import GOLD
+    g = dict(np.load(os.path.join(GOLD, "ref_c3.npz")))
+    flat = rt.FlatScene.from_json(scenes.c3_scene(str(tmp_path)))
+    sc = rt.Scene(flat, 0)
+    n = int(g["W"]) * int(g["H"])
+    r = sc.trace_batch(np.zeros((n, 3), np.float32), g["s"])
+    assert np.array_equal(r["hit"], g["hit"]) and np.array_equal(r["id"], g["id"]) and np.array_equal(bits(r["t"]), bits(g["t"]))
+    assert sc.last_stats["rays_nearest"] == int(g["rays_nearest"]) and sc.last_stats["rays_shadow"] == int(g["rays_shadow"])
+    d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(g["rgb"]).astype(int)).max(axis=1)
+    assert d8.max() <= 1 and np.nanmax(np.abs(r["rgb"] - g["rgb"])) < 2e-3
+    a = sc.intersect_batch(g["sec_e"], g["sec_d"])
+    assert np.array_equal(a["id"], g["sec_id"]) and np.array_equal(bits(a["t"]), bits(g["sec_t"]))
+    a = sc.shadow_batch(g["shd_p"], g["shd_l"])
+    assert np.array_equal(a["lit"], g["shd_lit"].astype(np.uint8))
+    lit = a["lit"] != 0
+    assert np.allclose(a["shadow"][lit], g["shd_shadow"][lit], rtol=1e-6, atol=0)
+    sc.close()
 
 
 def test_c3_nested_csg_depth5(tmp_path):

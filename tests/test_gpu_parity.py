@@ -81,6 +81,26 @@ def test_random_scene_vs_reference_dump(name, gpu_scenes, flat_scenes, golden):
         assert hit and np.abs(np.asarray(rgb) - g["rgb"][i]).max() < 1e-5 and text.count("object triangle hit at") >= 3
 
 
+def test_c2_family_vs_reference_dump(gpu_scenes, golden):
+    """The benchmark's workload family against the COMPILED REFERENCE: the C2 generator with 4 608 triangles at 160x90 from bench.py's
+    camera (tests/golden/ref_c2_48.npz).  Ids, t, ray counts exact; RGB within 1/255 except texels picked across a texel boundary on
+    the bump-mapped spheres (int(u*W) with u from atan2f / asinf, bump.cpp:14-23: device libm against glibc), counted."""
+    g = golden("c2_48")
+    n = int(g["W"]) * int(g["H"])
+    sc = gpu_scenes("c2_48")
+    e = np.tile(g["eye"].astype(np.float32), (n, 1))
+    r = sc.trace_batch(e, g["s"])
+    assert np.array_equal(r["hit"], g["hit"]) and np.array_equal(r["id"], g["id"]) and np.array_equal(bits(r["t"]), bits(g["t"]))
+    assert sc.last_stats["rays_nearest"] == int(g["rays_nearest"]) and sc.last_stats["rays_shadow"] == int(g["rays_shadow"])
+    d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(g["rgb"]).astype(int)).max(axis=1)
+    print(f"{int((d8 > 1).sum())} of {n} pixels beyond 1/255, {int((d8 > 0).sum())} differ at all")
+    assert (d8 > 1).mean() < 2e-3
+    a = sc.shadow_batch(g["shd_p"], g["shd_l"])
+    assert np.array_equal(a["lit"], g["shd_lit"].astype(np.uint8))
+    lit = a["lit"] != 0
+    assert np.allclose(a["shadow"][lit], g["shd_shadow"][lit], rtol=1e-6, atol=0)
+
+
 def test_scene_m_same_samples_as_oracle(gpu_scenes, flat_scenes, golden):
     # device and oracle share the counter-based generator, so with equal seeds they shade the same light samples
     g = golden("m")

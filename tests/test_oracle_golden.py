@@ -36,6 +36,59 @@ def test_secondary_and_shadow_rays_vs_reference(name, flat_scenes, golden):
     assert np.array_equal(bits(r["shadow"]), bits(g["shd_shadow"]))
 
 
+def test_c2_family_bit_exact_vs_reference(flat_scenes, golden):
+    """The generator of the benchmark's workload (BASELINE config 2: textured height field + two bump-mapped spheres, ambient +
+    directional + point light) with 4 608 triangles, 160x90 from bench.py's camera, run through the compiled reference
+    (tools/make_random_golden.py c2_48)."""
+    g = golden("c2_48")
+    n = int(g["W"]) * int(g["H"])
+    fs = flat_scenes("c2_48")
+    e = np.tile(g["eye"].astype(np.float32), (n, 1))
+    r = oracle.trace_batch(fs, e, g["s"], seed=0)
+    assert np.array_equal(r["hit"], g["hit"]) and np.array_equal(r["id"], g["id"]) and np.array_equal(bits(r["t"]), bits(g["t"]))
+    assert np.array_equal(bits(r["rgb"]), bits(g["rgb"]))
+    assert r["rays_nearest"] == int(g["rays_nearest"]) and r["rays_shadow"] == int(g["rays_shadow"])
+    a = oracle.shadow_batch(fs, g["shd_p"], g["shd_l"])
+    assert np.array_equal(a["lit"], g["shd_lit"].astype(np.uint8)) and np.array_equal(bits(a["shadow"]), bits(g["shd_shadow"]))
+
+
+def test_c2_full_size_bit_exact_vs_reference(tmp_path):
+    """The benchmark's scene itself (100 352 triangles, generated again by the deterministic generator), 256x144 from bench.py's camera."""
+    import os
+    import raytracer_amd as rt
+    from conftest import GOLD
+    from raytracer_amd import scenes
+    g = dict(np.load(os.path.join(GOLD, "ref_c2_224.npz")))
+    fs = rt.FlatScene.from_json(scenes.c2_scene(str(tmp_path)))
+    n = int(g["W"]) * int(g["H"])
+    e = np.tile(g["eye"].astype(np.float32), (n, 1))
+    r = oracle.trace_batch(fs, e, g["s"], seed=1, threads=4)          # no area lights: the seed does not matter
+    assert np.array_equal(r["hit"], g["hit"]) and np.array_equal(r["id"], g["id"]) and np.array_equal(bits(r["t"]), bits(g["t"]))
+    assert np.array_equal(bits(r["rgb"]), bits(g["rgb"]))
+    assert r["rays_nearest"] == int(g["rays_nearest"]) and r["rays_shadow"] == int(g["rays_shadow"])
+    a = oracle.intersect_batch(fs, g["sec_e"], g["sec_d"]) if len(g["sec_id"]) else None
+    assert a is None or (np.array_equal(a["id"], g["sec_id"]) and np.array_equal(bits(a["t"]), bits(g["sec_t"])))
+    a = oracle.shadow_batch(fs, g["shd_p"], g["shd_l"])
+    assert np.array_equal(a["lit"], g["shd_lit"].astype(np.uint8)) and np.array_equal(bits(a["shadow"]), bits(g["shd_shadow"]))
+
+
+def test_c3_bit_exact_vs_reference(tmp_path):
+    """BASELINE config 3 (64 nested CSG objects, half reflective, a quarter transmissive), 240x135, depth limit 16."""
+    import os
+    import raytracer_amd as rt
+    from conftest import GOLD
+    from raytracer_amd import scenes
+    g = dict(np.load(os.path.join(GOLD, "ref_c3.npz")))
+    fs = rt.FlatScene.from_json(scenes.c3_scene(str(tmp_path)))
+    n = int(g["W"]) * int(g["H"])
+    r = oracle.trace_batch(fs, np.zeros((n, 3), np.float32), g["s"], seed=1, threads=4)
+    assert np.array_equal(r["hit"], g["hit"]) and np.array_equal(r["id"], g["id"]) and np.array_equal(bits(r["t"]), bits(g["t"]))
+    assert np.array_equal(bits(r["rgb"]), bits(g["rgb"]))
+    assert r["rays_nearest"] == int(g["rays_nearest"]) and r["rays_shadow"] == int(g["rays_shadow"])
+    a = oracle.intersect_batch(fs, g["sec_e"], g["sec_d"])
+    assert np.array_equal(a["id"], g["sec_id"]) and np.array_equal(bits(a["t"]), bits(g["sec_t"]))
+
+
 def test_texel_state_of_rehit_textured_triangles(flat_scenes, golden):
     """random_5: two reflective meshes face each other, and a reflected ray's subtree comes back to the textured triangle it left.
     The reference then lights the outer hit with the texel of the LAST hit on that triangle (texturemesh.cpp:49-50 writes the

@@ -9,7 +9,8 @@ rand() in the reference's order (seed 0, one thread) so that area lights compare
 and float RGB bit for bit, the frame's BVH::findNearest / BVH::calcShadow call counts, and the sampled secondary rays and shadow
 queries the driver intercepted.
 
-usage: tools/fuzz_oracle_vs_ref.py [first_seed] [count] [objects per scene] [W] [H] [mixed | csg | <scale factor>]"""
+usage: tools/fuzz_oracle_vs_ref.py [first_seed] [count] [objects per scene] [W] [H] [mixed | csg | <scale factor> | c2:<grid> | c3 | c4:<samples>]
+(c2 / c3 / c4: the generators of the BASELINE configurations; the seed moves the camera)"""
 import ctypes
 import os
 import sys
@@ -21,7 +22,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import oracle  # noqa: E402
 import raytracer_amd as rt  # noqa: E402
-from make_golden import run_driver  # noqa: E402
+import subprocess  # noqa: E402
+from make_golden import DRIVER  # noqa: E402
+from refdump import read_ref_dump  # noqa: E402
 from raytracer_amd import scenes  # noqa: E402
 
 
@@ -29,15 +32,36 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
+def drive(name, W, H, cwd, camera=None):
+    """oracle/_ref/ref_driver on scenes/<name>.json below cwd, from the default camera or from (eye x, y, z, rotX, rotY)."""
+    out = tempfile.mktemp(suffix=".bin")
+    args = [DRIVER, name, str(W), str(H), out, "4096", "1"] + ([repr(float(v)) for v in camera] if camera else [])
+    subprocess.run(args, cwd=cwd, check=True, capture_output=True)
+    r = read_ref_dump(out)
+    os.remove(out)
+    return r
+
+
 def one(seed, n_objects, W, H, kind="mixed"):
+    camera = None
     with tempfile.TemporaryDirectory() as tmp:
+        d = os.path.join(tmp, "scenes")
         if kind == "csg":       # random operator trees of up to 16 leaves (multi-interval lists, empty operands)
-            path = scenes.random_csg_scene(os.path.join(tmp, "scenes"), seed=seed, n_objects=n_objects)
+            path = scenes.random_csg_scene(d, seed=seed, n_objects=n_objects)
+        elif kind.startswith("c2"):   # the BASELINE workloads themselves, at sizes the reference finishes in seconds: `seed` varies the camera
+            path = scenes.c2_scene(d, grid=int(kind[3:] or 24))
+            camera = (0.3 * seed, 1.5, 1.0 - 0.2 * seed, -0.3, 0.05 * seed)
+        elif kind == "c3":
+            path = scenes.c3_scene(d)
+            camera = (0.2 * seed, 1.5 + 0.1 * seed, 2.0, -0.35, 0.04 * seed)
+        elif kind.startswith("c4"):
+            path = scenes.c4_scene(d, samples=int(kind[3:] or 4))
+            camera = (0.1 * seed, 0.0, 0.0, 0.0, 0.02 * seed)
         else:
-            path = scenes.random_scene(os.path.join(tmp, "scenes"), seed=seed, n_objects=n_objects)
+            path = scenes.random_scene(d, seed=seed, n_objects=n_objects)
             if kind != "mixed":     # every length scaled: the reference's absolute epsilons against tiny / huge geometry
                 path = scenes.scale_scene(path, float(kind))
-        g = run_driver(os.path.basename(path)[:-5], W, H, 4096, cwd=tmp)
+        g = drive(os.path.basename(path)[:-5], W, H, tmp, camera)
         flat = rt.FlatScene.from_json(path)
     n = W * H
     ctypes.CDLL(None).srand(1)
@@ -45,7 +69,8 @@ def one(seed, n_objects, W, H, kind="mixed"):
     cases.restype = ctypes.c_uint64
     cases(1)
     oracle.texel_cases()
-    r = oracle.trace_batch(flat, np.zeros((n, 3), np.float32), g["s"], seed=0, threads=1)
+    eyes = np.tile(g["eye"].astype(np.float32), (n, 1))
+    r = oracle.trace_batch(flat, eyes, g["s"], seed=0, threads=1)
     frame_cases = int(cases(1))
     texel_cases = oracle.texel_cases()
     # pixels that differ in anything: did their ray tree run into an exit search that found no exit?  (There the reference goes on
@@ -53,7 +78,7 @@ def one(seed, n_objects, W, H, kind="mixed"):
     differing = np.where((r["hit"] != g["hit"]) | (r["id"] != g["id"]) | (bits(r["t"]) != bits(g["t"])) | (bits(r["rgb"]) != bits(g["rgb"])).any(axis=1))[0]
     unexplained = 0
     for i in differing:
-        oracle.trace_batch(flat, np.zeros((1, 3), np.float32), g["s"][i:i + 1], seed=0, threads=1)
+        oracle.trace_batch(flat, eyes[:1], g["s"][i:i + 1], seed=0, threads=1)
         unexplained += int(cases(1)) == 0
     res = {
         "differing": len(differing), "unexplained": unexplained, "frame_cases": frame_cases, "texel_cases": texel_cases,

@@ -3,7 +3,11 @@
 `make -C oracle ref`; container only) on scenes of raytracer_amd.scenes.random_scene -- every primitive, material and light kind at once,
 which the thirteen bundled scenes do not offer -- at 96x64 from the default camera, in the format of tools/make_golden.py.  The reference loads
 the generated JSON from a temporary directory (its scene path is the relative literal "scenes/", raytracer.cpp:22).
-usage: tools/make_random_golden.py seed [seed ...]        (seeds whose scene has no area light: those draw from rand())"""
+usage: tools/make_random_golden.py seed [seed ...]        (seeds whose scene has no area light: those draw from rand())
+       tools/make_random_golden.py c2_<grid>             -> ref_c2_<grid>.npz: the C2 generator (textured height field of grid*grid*2 triangles, two
+                                                            bump-mapped spheres) at 160x90 from bench.py's camera; c2_224 = the full-size
+                                                            benchmark scene at 256x144, outputs only
+       tools/make_random_golden.py c3                    -> ref_c3.npz: BASELINE config 3 at 240x135, outputs only"""
 import ctypes as C
 import gzip
 import json
@@ -21,7 +25,34 @@ from raytracer_amd import scenes  # noqa: E402
 
 if __name__ == "__main__":
     lib = C.CDLL(os.path.join(ROOT, "raytracer_amd", "lib", "libraytracer_amd.so"))
-    for seed in (int(a) for a in sys.argv[1:]):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    for name in [a for a in sys.argv[1:] if a.startswith("c2_")]:
+        from fuzz_oracle_vs_ref import drive
+        with tempfile.TemporaryDirectory() as tmp:
+            path = scenes.c2_scene(os.path.join(tmp, "scenes"), grid=int(name[3:]))
+            big = int(name[3:]) > 64     # the full-size scene is not stored: the tests generate it again (the generator is deterministic)
+            W, H = (256, 144) if big else (160, 90)
+            r = drive(os.path.basename(path)[:-5], W, H, tmp, camera=(0.0, 1.5, 1.0, -0.3, 0.0))
+            np.savez_compressed(os.path.join(GOLD, f"ref_{name}.npz"), **r)
+            if big:
+                print(f"{name}: {W}x{H}, {r['rays_nearest']} nearest, {r['rays_shadow']} shadow rays", flush=True)
+                continue
+            fs = C.c_void_p()
+            assert lib.rt_load_scene_json(path.encode(), None, C.byref(fs)) == 0
+            flat = os.path.join(tmp, "flat.rtscene")
+            assert lib.rt_flat_scene_save(fs, flat.encode()) == 0
+            lib.rt_flat_scene_free(fs)
+            with open(flat, "rb") as f, gzip.GzipFile(os.path.join(GOLD, "scenes", f"{name}.rtscene.gz"), "wb", mtime=0) as g:
+                shutil.copyfileobj(f, g)
+        print(f"{name}: {W}x{H}, {r['rays_nearest']} nearest, {r['rays_shadow']} shadow rays", flush=True)
+    if "c3" in sys.argv[1:]:     # BASELINE config 3 (64 nested CSG objects), default camera, the reference's own depth limit of 16; outputs only
+        from fuzz_oracle_vs_ref import drive
+        with tempfile.TemporaryDirectory() as tmp:
+            path = scenes.c3_scene(os.path.join(tmp, "scenes"))
+            r = drive(os.path.basename(path)[:-5], 240, 135, tmp)
+            np.savez_compressed(os.path.join(GOLD, "ref_c3.npz"), **r)
+        print(f"c3: 240x135, {r['rays_nearest']} nearest, {r['rays_shadow']} shadow rays", flush=True)
+    for seed in (int(a) for a in sys.argv[1:] if not a.startswith("c")):
         with tempfile.TemporaryDirectory() as tmp:
             path = scenes.random_scene(os.path.join(tmp, "scenes"), seed=seed, n_objects=40)
             kinds = {l["type"] for l in json.load(open(path))["lights"]}

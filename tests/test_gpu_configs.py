@@ -127,6 +127,39 @@ def test_c2_ray_counts_vs_oracle_reduced_frame(c2):
     assert (d8 > 1).mean() < 2e-3
 
 
+def _against_dump(sc, g, rgb_exact=True):
+    n = int(g["W"]) * int(g["H"])
+    e = np.tile(g["eye"].astype(np.float32), (n, 1))
+    r = sc.trace_batch(e, g["s"])
+    assert np.array_equal(r["hit"], g["hit"]) and np.array_equal(r["id"], g["id"]) and np.array_equal(bits(r["t"]), bits(g["t"]))
+    assert sc.last_stats["rays_nearest"] == int(g["rays_nearest"]) and sc.last_stats["rays_shadow"] == int(g["rays_shadow"])
+    d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(g["rgb"]).astype(int)).max(axis=1)
+    assert d8.max() <= 1 and np.nanmax(np.abs(r["rgb"] - g["rgb"])) < 2e-3
+    if len(g["sec_id"]):
+        a = sc.intersect_batch(g["sec_e"], g["sec_d"])
+        assert np.array_equal(a["id"], g["sec_id"]) and np.array_equal(bits(a["t"]), bits(g["sec_t"]))
+    a = sc.shadow_batch(g["shd_p"], g["shd_l"])
+    assert np.array_equal(a["lit"], g["shd_lit"].astype(np.uint8))
+    lit = a["lit"] != 0
+    assert np.allclose(a["shadow"][lit], g["shd_shadow"][lit], rtol=1e-6, atol=0)
+    return r
+
+
+def test_fat_leaves_and_lone_meshes_vs_compiled_reference(tmp_path):
+    """Two more dumps of the COMPILED REFERENCE (tools/make_random_golden.py c5_300 mesh_3, scenes generated again here):
+    a C5-style mesh of 180 000 triangles, which the reference's depth cap of 16 leaves in 65 536 leaves of up to 3 triangles and the
+    device walks through conservative sub-trees, and the scene of meshes asked for hits on their own (Mesh::rayhit: a refractive
+    mesh, a mesh as CSG operand; per-mesh trees on the device).  192x108 each: ids, t, ray counts exact, RGB within 1/255."""
+    import os
+    from conftest import GOLD
+    for name, make in (("c5_300", lambda d: scenes.c5_scene(d, grid=300, binary=False)), ("mesh_3", lambda d: scenes.mesh_scene(d, subdiv=3))):
+        g = dict(np.load(os.path.join(GOLD, f"ref_{name}.npz")))
+        flat = rt.FlatScene.from_json(make(str(tmp_path / name)))
+        sc = rt.Scene(flat, 0)
+        _against_dump(sc, g)
+        sc.close()
+
+
 def test_c3_vs_compiled_reference(tmp_path):
     """BASELINE config 3 against what the COMPILED REFERENCE computed for it at 240x135 (tests/golden/ref_c3.npz, the reference's own
     depth limit of 16): ids, t, ray counts exact, RGB within 1/255; sampled secondary rays and shadow queries."""

@@ -89,6 +89,25 @@ def test_c3_bit_exact_vs_reference(tmp_path):
     assert np.array_equal(a["id"], g["sec_id"]) and np.array_equal(bits(a["t"]), bits(g["sec_t"]))
 
 
+@pytest.mark.parametrize("name", ["c5_300", "mesh_3"])
+def test_fat_leaves_and_lone_meshes_bit_exact_vs_reference(name, tmp_path):
+    """A C5-style mesh of 180 000 triangles (the reference's depth cap of 16 leaves several triangles per leaf) and the scene of
+    meshes asked for hits on their own (Mesh::rayhit), 192x108 each."""
+    import os
+    import raytracer_amd as rt
+    from conftest import GOLD
+    from raytracer_amd import scenes
+    g = dict(np.load(os.path.join(GOLD, f"ref_{name}.npz")))
+    path = scenes.c5_scene(str(tmp_path), grid=300, binary=False) if name == "c5_300" else scenes.mesh_scene(str(tmp_path), subdiv=3)
+    fs = rt.FlatScene.from_json(path)
+    n = int(g["W"]) * int(g["H"])
+    e = np.tile(g["eye"].astype(np.float32), (n, 1))
+    r = oracle.trace_batch(fs, e, g["s"], seed=1, threads=4)
+    assert np.array_equal(r["hit"], g["hit"]) and np.array_equal(r["id"], g["id"]) and np.array_equal(bits(r["t"]), bits(g["t"]))
+    assert np.array_equal(bits(r["rgb"]), bits(g["rgb"]))
+    assert r["rays_nearest"] == int(g["rays_nearest"]) and r["rays_shadow"] == int(g["rays_shadow"])
+
+
 def test_texel_state_of_rehit_textured_triangles(flat_scenes, golden):
     """random_5: two reflective meshes face each other, and a reflected ray's subtree comes back to the textured triangle it left.
     The reference then lights the outer hit with the texel of the LAST hit on that triangle (texturemesh.cpp:49-50 writes the

@@ -9,7 +9,7 @@ rand() in the reference's order (seed 0, one thread) so that area lights compare
 and float RGB bit for bit, the frame's BVH::findNearest / BVH::calcShadow call counts, and the sampled secondary rays and shadow
 queries the driver intercepted.
 
-usage: tools/fuzz_oracle_vs_ref.py [first_seed] [count] [objects per scene] [W] [H] [mixed | csg | <scale factor> | c2:<grid> | c3 | c4:<samples>]
+usage: tools/fuzz_oracle_vs_ref.py [first_seed] [count] [objects per scene] [W] [H] [mixed | csg | <scale factor> | c2:<grid> | c3 | c4:<samples> | c5:<grid> | mesh:<subdivisions>]
 (c2 / c3 / c4: the generators of the BASELINE configurations; the seed moves the camera)"""
 import ctypes
 import os
@@ -51,6 +51,12 @@ def one(seed, n_objects, W, H, kind="mixed"):
         elif kind.startswith("c2"):   # the BASELINE workloads themselves, at sizes the reference finishes in seconds: `seed` varies the camera
             path = scenes.c2_scene(d, grid=int(kind[3:] or 24))
             camera = (0.3 * seed, 1.5, 1.0 - 0.2 * seed, -0.3, 0.05 * seed)
+        elif kind.startswith("c5"):   # a mesh the reference's depth cap of 16 leaves in fat leaves (above 131 072 triangles), as JSON
+            path = scenes.c5_scene(d, grid=int(kind[3:] or 300), binary=False)
+            camera = (0.3 * seed, 1.5, 1.0 - 0.2 * seed, -0.3, 0.05 * seed)
+        elif kind.startswith("mesh"):   # meshes asked for hits on their own (Mesh::rayhit): a refractive mesh, a mesh as a CSG operand
+            path = scenes.mesh_scene(d, subdiv=int(kind[5:] or 2))
+            camera = (0.2 * seed, 0.1 * seed, 0.0, 0.0, 0.03 * seed)
         elif kind == "c3":
             path = scenes.c3_scene(d)
             camera = (0.2 * seed, 1.5 + 0.1 * seed, 2.0, -0.35, 0.04 * seed)

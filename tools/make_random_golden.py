@@ -7,7 +7,8 @@ usage: tools/make_random_golden.py seed [seed ...]        (seeds whose scene has
        tools/make_random_golden.py c2_<grid>             -> ref_c2_<grid>.npz: the C2 generator (textured height field of grid*grid*2 triangles, two
                                                             bump-mapped spheres) at 160x90 from bench.py's camera; c2_224 = the full-size
                                                             benchmark scene at 256x144, outputs only
-       tools/make_random_golden.py c3                    -> ref_c3.npz: BASELINE config 3 at 240x135, outputs only"""
+       tools/make_random_golden.py c3                    -> ref_c3.npz: BASELINE config 3 at 240x135, outputs only
+       tools/make_random_golden.py c5_300 | mesh_3       -> a C5-style mesh of 180 000 triangles / the scene of meshes asked for hits on their own, 192x108, outputs only"""
 import ctypes as C
 import gzip
 import json
@@ -52,7 +53,21 @@ if __name__ == "__main__":
             r = drive(os.path.basename(path)[:-5], 240, 135, tmp)
             np.savez_compressed(os.path.join(GOLD, "ref_c3.npz"), **r)
         print(f"c3: 240x135, {r['rays_nearest']} nearest, {r['rays_shadow']} shadow rays", flush=True)
-    for seed in (int(a) for a in sys.argv[1:] if not a.startswith("c")):
+    if "c5_300" in sys.argv[1:]:     # a mesh of 180 000 triangles: the reference's depth cap of 16 leaves it in leaves of up to 3 triangles ... 131 072 leaves
+        from fuzz_oracle_vs_ref import drive
+        with tempfile.TemporaryDirectory() as tmp:
+            path = scenes.c5_scene(os.path.join(tmp, "scenes"), grid=300, binary=False)
+            r = drive(os.path.basename(path)[:-5], 192, 108, tmp, camera=(0.0, 1.5, 1.0, -0.3, 0.0))
+            np.savez_compressed(os.path.join(GOLD, "ref_c5_300.npz"), **r)
+        print(f"c5_300: 192x108, {r['rays_nearest']} nearest, {r['rays_shadow']} shadow rays", flush=True)
+    if "mesh_3" in sys.argv[1:]:     # meshes asked for hits on their own (Mesh::rayhit): a refractive mesh, a mesh as a CSG operand
+        from fuzz_oracle_vs_ref import drive
+        with tempfile.TemporaryDirectory() as tmp:
+            path = scenes.mesh_scene(os.path.join(tmp, "scenes"), subdiv=3)
+            r = drive(os.path.basename(path)[:-5], 192, 108, tmp)
+            np.savez_compressed(os.path.join(GOLD, "ref_mesh_3.npz"), **r)
+        print(f"mesh_3: 192x108, {r['rays_nearest']} nearest, {r['rays_shadow']} shadow rays", flush=True)
+    for seed in (int(a) for a in sys.argv[1:] if a.isdigit()):
         with tempfile.TemporaryDirectory() as tmp:
             path = scenes.random_scene(os.path.join(tmp, "scenes"), seed=seed, n_objects=40)
             kinds = {l["type"] for l in json.load(open(path))["lights"]}

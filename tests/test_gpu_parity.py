@@ -141,6 +141,22 @@ def test_render_frame_vs_oracle(name, aa, gpu_scenes, flat_scenes):
     assert sc.last_stats["rays_nearest"] == nn and sc.last_stats["rays_shadow"] == ns
 
 
+def test_frames_from_moved_and_turned_cameras(gpu_scenes):
+    """k_generate against the compiled reference's primary rays (tests/golden/ref_cameras.npz: setFacing() and s(x, y), q1.cpp:30-53, for
+    twenty cameras): the frame path gives, bit for bit, what rt_trace_batch gives for the reference's own eye and targets."""
+    import os
+    import raytracer_amd as rt
+    from conftest import GOLD
+    g = np.load(os.path.join(GOLD, "ref_cameras.npz"))
+    sc = gpu_scenes("h")
+    for k, c in enumerate(g["cameras"]):
+        for W, H in ((16, 9), (7, 13)):
+            cam = rt.Camera(float(g["fov"]), W, H, eye=tuple(c[:3]), rot_x=float(c[3]), rot_y=float(c[4]))
+            img = sc.render(W, H, camera=cam)
+            r = sc.trace_batch(np.tile(g[f"eye_{k}_{W}x{H}"], (W * H, 1)), g[f"s_{k}_{W}x{H}"])
+            assert np.array_equal(bits(img.reshape(-1, 3)), bits(r["rgb"])), (k, W, H)
+
+
 def test_render_is_deterministic_and_tiles_compose(gpu_scenes, flat_scenes):
     import torch
     import raytracer_amd as rt

@@ -131,6 +131,21 @@ def test_binary_scene_round_trip_and_corruption(flat_scenes, scene_dir, tmp_path
         rt.FlatScene.load(str(tmp_path / "magic.rtscene"))
 
 
+def test_moved_and_turned_cameras_match_the_reference():
+    """rt_camera_setup and the primary targets against the compiled reference's setFacing() / s(x, y) (q1.cpp:30-53) for twenty cameras:
+    eye positions, rotations about both axes, angles q1.cpp snaps to zero (tests/golden/ref_cameras.npz, tools/make_camera_golden.py)."""
+    import os
+    import oracle
+    from conftest import GOLD
+    g = np.load(os.path.join(GOLD, "ref_cameras.npz"))
+    for k, c in enumerate(g["cameras"]):
+        for W, H in ((16, 9), (7, 13)):
+            cam = rt.Camera(float(g["fov"]), W, H, eye=tuple(c[:3]), rot_x=float(c[3]), rot_y=float(c[4]))
+            for field in ("eye", "facing", "right", "up"):
+                assert np.array_equal(np.array(getattr(cam.c, field)[:], np.float32).view(np.uint32), g[f"{field}_{k}_{W}x{H}"].view(np.uint32)), (k, field)
+            assert np.array_equal(oracle.primary_targets(cam, W, H).view(np.uint32), g[f"s_{k}_{W}x{H}"].view(np.uint32)), k
+
+
 def test_camera_matches_reference_dump(golden):
     g = golden("i")          # fov 75
     cam = rt.Camera(float(g["fov"]), int(g["W"]), int(g["H"]))

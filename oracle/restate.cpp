@@ -588,8 +588,9 @@ struct Tracer {
 			V3 texColour(float(px[0]) / 255, float(px[1]) / 255, float(px[2]) / 255);
 			material.ambient[0] = texColour.x; material.ambient[1] = texColour.y; material.ambient[2] = texColour.z;
 			material.diffuse[0] = texColour.x; material.diffuse[1] = texColour.y; material.diffuse[2] = texColour.z;
-			texelOf[ix] = texColour;   // texturemesh.cpp:49-50 writes the TRIANGLE's own material: state that outlives this call
-			textured = true;
+			// texturemesh.cpp:49-50 writes the TRIANGLE's own material: state that outlives this call.  It is only ever read back
+			// by a hit on the same triangle whose reflected ray has been traced in between, i.e. when the material reflects.
+			if (!isZero(material.reflective)) { texelOf[ix] = texColour; textured = true; }
 		}
 
 		V3 V = normalize(-d);

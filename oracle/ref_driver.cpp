@@ -128,6 +128,41 @@ int main(int argc, char** argv) {
 	eye = point3(0, 0, 0);
 	if (argc > 11) { eye = point3(atof(argv[7]), atof(argv[8]), atof(argv[9])); rotX = atof(argv[10]); rotY = atof(argv[11]); }
 
+	// rays mode: ref_driver <scene> 0 0 rays <in.bin> <out.bin> -- BVH::findNearest (bvh.cpp:72) and BVH::calcShadow (bvh.cpp:123) for
+	// caller-supplied queries.  in: uint64 n, n x {e[3], d[3]}, uint64 m, m x {p[3], l[3]} (floats); out: n x {int32 id, float t},
+	// m x {int32 lit, float shadow[3]} (shadow starts at (1, 1, 1) as in the light classes, objects.cpp:402).
+	if (strcmp(outPath, "rays") == 0) {
+		if (argc < 7) { fprintf(stderr, "usage: ref_driver <scene> 0 0 rays <in.bin> <out.bin>\n"); return 1; }
+		choose_scene(sceneName);
+		build_ids();
+		FILE* in = fopen(argv[5], "rb");
+		FILE* out = fopen(argv[6], "wb");
+		if (!in || !out) { perror("rays files"); return 2; }
+		uint64_t n = 0, m = 0;
+		if (fread(&n, 8, 1, in) != 1) return 2;
+		std::vector<float> q(n * 6);
+		if (n && fread(q.data(), 24, n, in) != n) return 2;
+		for (uint64_t i = 0; i < n; i++) {
+			point3 e(q[6 * i], q[6 * i + 1], q[6 * i + 2]), d(q[6 * i + 3], q[6 * i + 4], q[6 * i + 5]);
+			Object* h = bvh->findNearest(e, d);
+			int32_t hid = h ? g_ids[h] : -1;
+			float t = h ? h->rayhit(e, d, false) : 0.0f;
+			put(out, &hid, 4); put(out, &t, 4);
+		}
+		if (fread(&m, 8, 1, in) != 1) return 2;
+		q.resize(m * 6);
+		if (m && fread(q.data(), 24, m, in) != m) return 2;
+		for (uint64_t i = 0; i < m; i++) {
+			point3 pt(q[6 * i], q[6 * i + 1], q[6 * i + 2]), l(q[6 * i + 3], q[6 * i + 4], q[6 * i + 5]);
+			colour3 shadow(1.0, 1.0, 1.0);
+			int32_t lit = bvh->calcShadow(pt, l, shadow) ? 1 : 0;
+			float sh[3] = { shadow[0], shadow[1], shadow[2] };
+			put(out, &lit, 4); put(out, sh, 12);
+		}
+		fclose(in); fclose(out);
+		return 0;
+	}
+
 	// pick mode: ref_driver <scene> <W> <H> pick x y [x y ...] -- the reference's own narration of trace(..., pick = true)
 	// (raytracer.cpp:307-327, objects.cpp:54-140) for those pixels, on stdout, one "== pixel x y" header each
 	if (strcmp(outPath, "pick") == 0) {

@@ -101,6 +101,23 @@ def test_c2_family_vs_reference_dump(gpu_scenes, golden):
     assert np.allclose(a["shadow"][lit], g["shd_shadow"][lit], rtol=1e-6, atol=0)
 
 
+def test_awkward_rays_vs_reference_dump(gpu_scenes):
+    """rt_intersect_batch / rt_shadow_batch against the COMPILED REFERENCE's BVH::findNearest / BVH::calcShadow for 20 000 awkward rays on
+    the random_5 scene (zero, denormal, tiny and huge direction components, no direction at all, origins on box faces) and 8 820 shadow
+    queries from their hit points (tests/golden/ref_rays_random_5.npz): ids and lit flags exact, t bit for bit."""
+    import os
+    from conftest import GOLD
+    g = np.load(os.path.join(GOLD, "ref_rays_random_5.npz"))
+    sc = gpu_scenes("random_5")
+    r = sc.intersect_batch(g["e"], g["d"])
+    hit = g["id"] >= 0
+    assert np.array_equal(r["hit"] != 0, hit) and np.array_equal(r["id"][hit], g["id"][hit]) and np.array_equal(bits(r["t"][hit]), bits(g["t"][hit]))
+    a = sc.shadow_batch(g["p"], g["l"])
+    lit = g["lit"] != 0
+    assert np.array_equal(a["lit"], g["lit"])
+    assert np.allclose(a["shadow"][lit], g["shadow"][lit], rtol=1e-6, atol=0)
+
+
 def test_scene_m_same_samples_as_oracle(gpu_scenes, flat_scenes, golden):
     # device and oracle share the counter-based generator, so with equal seeds they shade the same light samples
     g = golden("m")

@@ -108,6 +108,22 @@ def test_fat_leaves_and_lone_meshes_bit_exact_vs_reference(name, tmp_path):
     assert r["rays_nearest"] == int(g["rays_nearest"]) and r["rays_shadow"] == int(g["rays_shadow"])
 
 
+def test_awkward_rays_bit_exact_vs_reference(flat_scenes):
+    """BVH::findNearest / BVH::calcShadow of the compiled reference for 20 000 awkward rays on the random_5 scene (zero, denormal, tiny and
+    huge direction components, no direction at all, origins on box faces) and 8 820 shadow queries from their hit points, every seventh
+    towards a light at the point itself (tests/golden/ref_rays_random_5.npz, tools/make_random_golden.py rays_5)."""
+    import os
+    from conftest import GOLD
+    g = np.load(os.path.join(GOLD, "ref_rays_random_5.npz"))
+    fs = flat_scenes("random_5")
+    r = oracle.intersect_batch(fs, g["e"], g["d"])
+    hit = g["id"] >= 0
+    assert np.array_equal(r["hit"] != 0, hit) and np.array_equal(r["id"][hit], g["id"][hit]) and np.array_equal(bits(r["t"][hit]), bits(g["t"][hit]))
+    a = oracle.shadow_batch(fs, g["p"], g["l"])
+    lit = g["lit"] != 0
+    assert np.array_equal(a["lit"], g["lit"]) and np.array_equal(bits(a["shadow"][lit]), bits(g["shadow"][lit]))
+
+
 def test_texel_state_of_rehit_textured_triangles(flat_scenes, golden):
     """random_5: two reflective meshes face each other, and a reflected ray's subtree comes back to the textured triangle it left.
     The reference then lights the outer hit with the texel of the LAST hit on that triangle (texturemesh.cpp:49-50 writes the

@@ -8,7 +8,9 @@ usage: tools/make_random_golden.py seed [seed ...]        (seeds whose scene has
                                                             bump-mapped spheres) at 160x90 from bench.py's camera; c2_224 = the full-size
                                                             benchmark scene at 256x144, outputs only
        tools/make_random_golden.py c3                    -> ref_c3.npz: BASELINE config 3 at 240x135, outputs only
-       tools/make_random_golden.py c5_300 | mesh_3       -> a C5-style mesh of 180 000 triangles / the scene of meshes asked for hits on their own, 192x108, outputs only"""
+       tools/make_random_golden.py c5_300 | mesh_3       -> a C5-style mesh of 180 000 triangles / the scene of meshes asked for hits on their own, 192x108, outputs only
+       tools/make_random_golden.py rays_<seed>           -> ref_rays_random_<seed>.npz: BVH::findNearest / BVH::calcShadow of the reference for 20 000 awkward rays
+                                                            (scenes.awkward_rays) and shadow queries from their hit points, on the random scene of that seed"""
 import ctypes as C
 import gzip
 import json
@@ -20,7 +22,7 @@ import tempfile
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from make_golden import GOLD, run_driver  # noqa: E402
 from raytracer_amd import scenes  # noqa: E402
 
@@ -67,6 +69,24 @@ if __name__ == "__main__":
             r = drive(os.path.basename(path)[:-5], 192, 108, tmp)
             np.savez_compressed(os.path.join(GOLD, "ref_mesh_3.npz"), **r)
         print(f"mesh_3: 192x108, {r['rays_nearest']} nearest, {r['rays_shadow']} shadow rays", flush=True)
+    for name in [a for a in sys.argv[1:] if a.startswith("rays_")]:   # rays_<seed>: awkward rays on the random scene of that seed (which must have its fixture)
+        from fuzz_rays_vs_ref import reference_queries
+        import oracle
+        import raytracer_amd as rt
+        seed = int(name[5:])
+        rng = np.random.default_rng(seed)
+        with tempfile.TemporaryDirectory() as tmp:
+            path = scenes.random_scene(os.path.join(tmp, "scenes"), seed=seed, n_objects=40)
+            e, d = scenes.awkward_rays(rng, 20000)
+            o = oracle.intersect_batch(rt.FlatScene.from_json(path), e, d)      # only to place the shadow queries on surfaces
+            hit = o["hit"].astype(bool)
+            p = (e + o["t"][:, None] * d)[hit].astype(np.float32)
+            p = p[np.isfinite(p).all(axis=1)]
+            l = rng.uniform([-4, 2, -9], [4, 6, 1], (len(p), 3)).astype(np.float32)
+            l[::7] = p[::7]
+            near, shad = reference_queries(os.path.basename(path)[:-5], tmp, e, d, p, l)
+        np.savez_compressed(os.path.join(GOLD, f"ref_rays_random_{seed}.npz"), e=e, d=d, id=near["id"], t=near["t"], p=p, l=l, lit=shad["lit"].astype(np.uint8), shadow=shad["shadow"])
+        print(f"{name}: {len(e)} nearest queries ({int((near['id'] >= 0).sum())} hits), {len(p)} shadow queries", flush=True)
     for seed in (int(a) for a in sys.argv[1:] if a.isdigit()):
         with tempfile.TemporaryDirectory() as tmp:
             path = scenes.random_scene(os.path.join(tmp, "scenes"), seed=seed, n_objects=40)

@@ -529,6 +529,10 @@ struct Tracer {
 			return true;
 		}
 		V3 currentPoint = inPoint, innerVector, outNormal;
+		// csgObject::getNormal returns the member cachedHitNormal, which a failed exit search does not touch: it still holds the normal
+		// of the last successful rayhit on the object -- the hit this ray entered through, unless a shadow ray of the same hit went
+		// through the object in between (STATE).  (The other classes write into the caller's uninitialised local.)
+		if (type == RT_PRIM_CSG) outNormal = inNormal;
 		refractRay(inVector, inNormal, m.refraction, innerVector);
 		bool result = false;
 		int reflections = 0;

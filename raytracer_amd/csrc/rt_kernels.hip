@@ -1024,7 +1024,12 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 	f3 currentPoint = inPoint, innerVector = mk3(0, 0, 0), outNormal = mk3(0, 0, 0);
 	refractRay(inVector, inNormal, refraction, innerVector);
 	rt_csg c = {};
-	if (CSG && type == RT_PRIM_CSG) { c = S.csgs[ix]; csgStore.loadProgram(S, c); }
+	if (CSG && type == RT_PRIM_CSG) {
+		c = S.csgs[ix]; csgStore.loadProgram(S, c);
+		// csgObject::getNormal returns the member cachedHitNormal, which a failed exit search leaves alone: the normal of the last
+		// successful rayhit on the object, i.e. of the hit this ray entered through (the other classes write into transmitRay's local)
+		outNormal = inNormal;
+	}
 	bool result = false;
 	int reflections = 0;
 	while (!result && reflections < RT_MAX_REFLECTIONS) {

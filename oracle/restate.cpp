@@ -542,7 +542,17 @@ struct Tracer {
 			float tExit = 0;
 			switch (type) {
 			case RT_PRIM_SPHERE: { const rt_sphere& s = S->spheres[ix]; tExit = sphereHit(V3(s.center), s.radius, currentPoint, innerVector, true, hp); outNormal = sphereNormal(s, hp); break; }
-			case RT_PRIM_TRI: { V3 nrm = outNormal; tExit = meshHit(S->meshes[S->tris[ix].mesh], currentPoint, innerVector, true, hp, nrm); outNormal = nrm; break; }   // STATE: cachedHitNormal
+			case RT_PRIM_TRI: {
+				// Mesh::cachedHitpoint / cachedHitNormal of a top-level mesh are written by exit searches only, and a failed one goes on
+				// from what the last successful one left -- of an EARLIER ray, possibly an earlier pixel (STATE).  With seed 0 (one thread,
+				// rays in the reference's order: the mode that is compared with the reference) that state is carried along; otherwise, and
+				// on the device, the fallback is the current point and the previous normal.
+				const int mi = S->tris[ix].mesh;
+				V3 nrm = outNormal;
+				if (seed == 0) { auto it = meshCache.find(mi); if (it != meshCache.end()) { hp = it->second.first; nrm = it->second.second; } }
+				tExit = meshHit(S->meshes[mi], currentPoint, innerVector, true, hp, nrm);
+				if (seed == 0 && tExit > 0) meshCache[mi] = std::make_pair(hp, nrm);
+				outNormal = nrm; break; }
 			case RT_PRIM_BOX: tExit = boxHit(S->boxes[ix].b, currentPoint, innerVector, true, hp); boxNormal(S->boxes[ix].b, hp, outNormal); break;
 			case RT_PRIM_CSG: { V3 nrm = outNormal; tExit = csgHit(S->csgs[ix], currentPoint, innerVector, true, hp, nrm); outNormal = nrm; break; }   // STATE on a miss
 			}
@@ -560,6 +570,7 @@ struct Tracer {
 		return result;
 	}
 
+	mutable std::unordered_map<int, std::pair<V3, V3>> meshCache;   // Mesh::cachedHitpoint / cachedHitNormal (seed 0 only, see transmitRay)
 	std::unordered_map<uint32_t, V3> texelOf;   // TextureTriangle::material.ambient / .diffuse as the last lightPoint on it left them
 
 	// ---- trace raytracer.cpp:307-329 + Object::lightPoint objects.cpp:54-105 + TextureTriangle::lightPoint texturemesh.cpp:25-52 ----

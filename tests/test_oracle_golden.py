@@ -192,8 +192,9 @@ def test_640x480_rgb8_and_ids(name, flat_scenes):
     rgb, nn, ns = oracle.render(fs, cam, 640, 480, seed=0, threads=4)
     q = np.clip(np.nan_to_num(rgb.reshape(-1, 3), nan=0.0), 0, 1)
     rgb8 = (q * np.float32(255) + np.float32(0.5)).astype(np.uint8)
-    # scene l: 2 of 307200 pixels depend on hit-cache state left by earlier rays in the reference (see restate.cpp "STATE")
-    allowed = 2 if name == "l" else 0
+    # scene l: 2 of 307200 pixels depend on the hit cache of the mesh as exit searches of EARLIER pixels left it (restate.cpp "STATE");
+    # with seed 0 -- one thread, the reference's ray order -- the restatement carries that state along and matches there too
+    allowed = 0
     assert (rgb8 != g["rgb8"]).any(axis=1).sum() <= allowed
     assert abs(nn - int(g["rays_nearest"])) <= allowed and abs(ns - int(g["rays_shadow"])) <= allowed
     if s is not None:

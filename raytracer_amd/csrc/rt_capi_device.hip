@@ -138,8 +138,17 @@ struct rt_scene {
 		return RT_OK;
 	}
 	int inFlight() const { int n = 0; for (const Job& j : jobs) if (j.id && j.remaining > 0) n++; return n; }
-	// waits until the lanes are idle (jobs may still be un-waited-for); call with mtx held
-	void drainLocked(std::unique_lock<std::mutex>& g) { cvDone.wait(g, [&] { return inFlight() == 0; }); }
+	// Waits until the lanes are idle AND the GPU has finished what they queued (jobs may still be un-waited-for); call with
+	// mtx held.  A worker is done with a shard once it has ENQUEUED it: the tail of the last level (shadow kernels, texel fix,
+	// resolve) may still be running on the lane's non-blocking stream, which neither the NULL stream nor another lane's
+	// stream is ordered behind -- so whoever goes on to use lane 0's queues or the shared accumulators waits for the
+	// shards' end events as well.  (Events of retired jobs are complete: rt_render_wait synchronised them.)
+	void drainLocked(std::unique_lock<std::mutex>& g) {
+		cvDone.wait(g, [&] { return inFlight() == 0; });
+		for (const Job& j : jobs)
+			if (j.id)
+				for (int k = 0; k < j.nShards; k++) (void)hipEventSynchronize(j.evDone[k]);
+	}
 	void drain() { std::unique_lock<std::mutex> g(mtx); drainLocked(g); }
 	int ensureAccum(uint32_t npix) {
 		if (accum.npix >= npix && accum.rgb) return RT_OK;
@@ -918,8 +927,11 @@ int rt_render_submit(rt_scene* sc, const rt_camera* camera, int width, int heigh
 	if (exclusive || tiles < 64 * nShards) nShards = 1;
 
 	std::unique_lock<std::mutex> g(sc->mtx);
-	rt_scene::Job* job = &sc->jobs[sc->nextId % RT_MAX_INFLIGHT];
-	if (job->id != 0) { rt::set_error("rt_render_submit: too many frames in flight (wait for an earlier ticket first)"); return RT_EINVAL; }
+	// any free slot (tickets may be waited for in any order); the ticket carries its slot: ticket % RT_MAX_INFLIGHT
+	rt_scene::Job* job = nullptr;
+	for (rt_scene::Job& j : sc->jobs) if (j.id == 0) { job = &j; break; }
+	if (!job) { rt::set_error("rt_render_submit: too many frames in flight (wait for an earlier ticket first)"); return RT_EINVAL; }
+	const uint64_t newTicket = sc->nextId * RT_MAX_INFLIGHT + (uint64_t)(job - sc->jobs);
 	// Shards of consecutive frames may overlap only if they own the same pixels of the shared accumulators
 	bool compatible = !exclusive && sc->accum.npix >= (uint32_t)(width * height) && sc->accum.rgb;
 	for (const rt_scene::Job& j : sc->jobs)
@@ -931,7 +943,8 @@ int rt_render_submit(rt_scene* sc, const rt_camera* camera, int width, int heigh
 	job->cam = *camera; job->W = width; job->H = height; job->aaX = aa_x; job->aaY = aa_y; job->maxDepth = max_depth;
 	job->tileRank = tile_rank; job->tileRanks = tile_ranks; job->nShards = nShards; job->seed = seed; job->flags = flags; job->rgb = rgb_dev; job->st = st;
 	HIPCHK(hipEventRecord(job->evStart, st));   // the lanes start after whatever the caller queued on its stream before this call
-	job->id = sc->nextId++;
+	job->id = newTicket;
+	sc->nextId++;
 	job->remaining = (int)sc->lanes.size();
 	for (size_t k = 0; k < sc->lanes.size(); k++) { job->rc[k] = RT_OK; job->err[k].clear(); job->part[k] = rt_stats{}; sc->laneQueue[k].push_back(job); }
 	*ticket = job->id;

@@ -94,3 +94,47 @@ def test_handle_freed_with_frames_in_flight(c2):
         sc.close()
         torch.cuda.synchronize()
         assert torch.equal(bufs[0], bufs[1]) and torch.equal(bufs[0], bufs[2]) and float(bufs[0].abs().sum()) > 0
+
+
+def test_tickets_waited_out_of_order_free_their_slots(c2):
+    """Up to 4 tickets outstanding, waited for in any order: a slot is free as soon as ITS ticket was waited for."""
+    flat, sc = c2
+    W, H = 480, 270
+    cam = rt.Camera(flat.fov, W, H, eye=(0, 1.5, 1.0), rot_x=-0.3)
+    bufs = [torch.zeros(H, W, 3, device="cuda") for _ in range(4)]
+    t = [sc.render_submit(bufs[i].data_ptr(), W, H, camera=cam) for i in range(4)]
+    for k in (1, 2, 3):
+        sc.render_wait(t[k])
+    more = [sc.render_submit(bufs[k].data_ptr(), W, H, camera=cam) for k in (1, 2, 3)]   # ticket t[0] is still outstanding
+    assert len(set(more + t)) == 7
+    sc.render_wait(t[0])
+    for m in reversed(more):
+        sc.render_wait(m)
+    assert all(torch.equal(bufs[0], b) for b in bufs[1:])
+
+
+def test_other_entry_points_wait_for_the_gpu_not_only_for_the_lanes(c2):
+    """A large frame, then a smaller one, neither waited for, then trace_batch: the batch uses lane 0's queues and the shared
+    accumulators, so it must wait until the GPU is through with the frames (not just until they are enqueued)."""
+    flat, sc = c2
+    big, small = torch.zeros(540, 960, 3, device="cuda"), torch.zeros(270, 480, 3, device="cuda")
+    cam_b, cam_s = rt.Camera(flat.fov, 960, 540, eye=(0, 1.5, 1.0), rot_x=-0.3), rt.Camera(flat.fov, 480, 270, eye=(0.2, 1.4, 1.0), rot_x=-0.25)
+    rng = np.random.default_rng(3)
+    e = (np.array([0, 1.5, 1.0], np.float32) + 0.05 * rng.normal(size=(4096, 3))).astype(np.float32)
+    s = (e + np.array([0, -0.3, -1.0], np.float32) + 0.2 * rng.normal(size=(4096, 3))).astype(np.float32)
+    want = sc.trace_batch(e, s)
+    rb, rs = torch.zeros_like(big), torch.zeros_like(small)
+    sc.render_into(rb.data_ptr(), 960, 540, camera=cam_b)
+    sc.render_into(rs.data_ptr(), 480, 270, camera=cam_s)
+    for _ in range(3):
+        big.zero_(); small.zero_()
+        tb = sc.render_submit(big.data_ptr(), 960, 540, camera=cam_b)
+        ts = sc.render_submit(small.data_ptr(), 480, 270, camera=cam_s)
+        got = sc.trace_batch(e, s)
+        sc.render_wait(ts)
+        sc.render_wait(tb)
+        assert torch.equal(big, rb) and torch.equal(small, rs)
+        for k in ("hit", "id"):
+            assert np.array_equal(got[k], want[k])
+        assert np.array_equal(got["t"].view(np.uint32), want["t"].view(np.uint32))
+        assert np.array_equal(got["rgb"].view(np.uint32), want["rgb"].view(np.uint32))

@@ -159,6 +159,22 @@ size_t rt_pick_narration(const rt_pick_event* events, size_t n, char* buf, size_
 int rt_intersect_batch(rt_scene* scene, const float* e, const float* d, size_t n, uint32_t flags,
                        uint8_t* hit, int32_t* obj_id, float* t, rt_stats* stats);
 
+/* NO COUNTERPART IN THE REFERENCE.  rt_intersect_batch for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and same results as rt_intersect_batch, but
+ *   - inputs and outputs are DEVICE buffers of the caller (e_dev, d_dev: n*3 floats; hit_dev n bytes, obj_id_dev n int32,
+ *     t_dev n floats; each output may be NULL),
+ *   - the ray queue, hit queue and counters the kernels work in are a file-scope device array of the library
+ *     (RT_STATIC_MAX_RAYS slots, 3.7 MB, held by every GPU the library runs on until the process ends): the call makes no
+ *     hipMalloc / hipFree and no allocating library call,
+ *   - n > RT_STATIC_MAX_RAYS is refused with RT_ELIMIT (split the batch),
+ *   - the work is enqueued on `stream` and NOT waited for: results are there once `stream` has reached this point.
+ * Every call on one GPU -- whatever the rt_scene handle -- shares that GPU's array: calls that overlap in time on one GPU
+ * (two streams, two threads) race.  Calls one after the other on one stream are fine; the array keeps the previous call's
+ * contents and the call clears what must start at zero. */
+#define RT_STATIC_MAX_RAYS 65536u
+int rt_intersect_batch_static(rt_scene* scene, const float* e_dev, const float* d_dev, size_t n,
+                              uint8_t* hit_dev, int32_t* obj_id_dev, float* t_dev, void* stream);
+
 /* shadowRay() for n queries (raytracer.h:18, raytracer.cpp:111-113 -> BVH::calcShadow, bvh.cpp:123-160):
  * lit[i] = return value, shadow[i] = the attenuation colour on return (starts at (1,1,1)). */
 int rt_shadow_batch(rt_scene* scene, const float* point, const float* light_pos, size_t n, uint32_t flags,

@@ -169,6 +169,11 @@ class Scene:
         self.last_stats = st.as_dict()
         return dict(hit=hit, id=oid, t=t)
 
+    def intersect_batch_static(self, e_dev_ptr, d_dev_ptr, n, hit_dev_ptr, id_dev_ptr, t_dev_ptr, stream=None):
+        """rt_intersect_batch_static: device buffers in and out, no allocation, enqueued on `stream` and not waited for."""
+        check(capi.load().rt_intersect_batch_static(self._h, C.c_void_p(e_dev_ptr), C.c_void_p(d_dev_ptr), int(n), C.c_void_p(hit_dev_ptr or 0),
+                                                    C.c_void_p(id_dev_ptr or 0), C.c_void_p(t_dev_ptr or 0), C.c_void_p(stream or 0)))
+
     def shadow_batch(self, point, light_pos, flags=0):
         """shadowRay for n queries (raytracer.cpp:111): returns dict(lit, shadow)."""
         p, l = f32(point, (-1, 3)), f32(light_pos, (-1, 3))

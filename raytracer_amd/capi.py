@@ -14,12 +14,13 @@ LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(_HERE, "lib", "libraytr
 RT_OK, RT_EINVAL, RT_EIO, RT_EPARSE, RT_EHIP, RT_ENOMEM, RT_ELIMIT = 0, -1, -2, -3, -4, -5, -6
 RT_FLAG_COUNTERS, RT_FLAG_TIME_KERNELS = 1, 2
 MAX_REFLECTIONS = 16
+RT_STATIC_MAX_RAYS = 65536
 
 # every symbol include/rt_capi.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "rt_load_scene_json", "rt_load_scene_json_text", "rt_flat_scene_save", "rt_flat_scene_load", "rt_flat_scene_free",
     "rt_camera_setup", "rt_write_bmp", "rt_quantize_rgb8", "rt_device_count", "rt_scene_upload", "rt_scene_free",
-    "rt_render", "rt_render_submit", "rt_render_wait", "rt_render_host", "rt_trace_batch", "rt_trace_pick", "rt_pick_narration", "rt_intersect_batch", "rt_shadow_batch", "rt_tiles_merge",
+    "rt_render", "rt_render_submit", "rt_render_wait", "rt_render_host", "rt_trace_batch", "rt_trace_pick", "rt_pick_narration", "rt_intersect_batch", "rt_intersect_batch_static", "rt_shadow_batch", "rt_tiles_merge",
     "rt_tiles_count", "rt_tiles_pack", "rt_tiles_unpack", "rt_last_error", "rt_version",
 ]
 
@@ -102,6 +103,7 @@ def load():
     lib.rt_pick_narration.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
     lib.rt_pick_narration.restype = C.c_size_t
     lib.rt_intersect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]
+    lib.rt_intersect_batch_static.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rt_shadow_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]
     for name in ("rt_tiles_pack", "rt_tiles_unpack", "rt_tiles_merge"):
         getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]

@@ -36,8 +36,42 @@ uint32_t envU32(const char* name, uint32_t dflt) {
 
 }  // namespace
 
+// ---- rt_intersect_batch_static: the entry point that allocates nothing (include/rt_capi.h) ------------------------------
+// Its scratch -- the ray queue, the hit queue and the counters that rt_intersect_batch takes from the handle's lane 0 -- is
+// this file-scope device array: every GPU the library runs on holds its own copy, at its own address, until the process
+// ends.  In host code the array's NAME is only a stand-in; the device address comes from hipGetSymbolAddress, once per
+// device (staticScratchFor, called by rt_scene_upload with that device current), and only that pointer is ever handed to
+// kernels and memsets.
+struct StaticScratch {
+	float ray[RQ_COMPS * RT_STATIC_MAX_RAYS];
+	float hit[HQ_COMPS * RT_STATIC_MAX_RAYS];
+	RtCounters ctr;
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(StaticScratch)];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratchMtx;
+StaticScratch* g_scratchPtr[kMaxDevices] = {};
+// the address of `scratch` on `device`, which must be the current device
+int staticScratchFor(int device, StaticScratch** out) {
+	*out = nullptr;
+	if (device < 0 || device >= kMaxDevices) { rt::set_error("device index beyond the static scratch table"); return RT_EINVAL; }
+	std::lock_guard<std::mutex> g(g_scratchMtx);
+	if (!g_scratchPtr[device]) {
+		void* p = nullptr;
+		HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+		if (!p) { rt::set_error("hipGetSymbolAddress returned a null address for the static scratch"); return RT_EHIP; }
+		g_scratchPtr[device] = static_cast<StaticScratch*>(p);
+	}
+	*out = g_scratchPtr[device];
+	return RT_OK;
+}
+}  // namespace
+
 struct rt_scene {
 	int device = 0;
+	StaticScratch* staticScratch = nullptr;   // this device's copy of `scratch` (rt_intersect_batch_static)
 	DevScene dev{};
 	bool hasCsg = false;
 	bool hasTransmissive = false;   // some material transmits: k_shade queues requests for k_transmit
@@ -781,6 +815,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	HIPCHK(hipGetDeviceProperties(&prop, device));
 	rt_scene* sc = new rt_scene();
 	sc->device = device;
+	if (int rcS = staticScratchFor(device, &sc->staticScratch)) { delete sc; return rcS; }
 	sc->maxBlocks = std::max(1, prop.multiProcessorCount) * (int)std::max<uint32_t>(1, envU32("RT_BLOCKS_PER_CU", 8));
 	sc->maxBlocksPacketNear = std::max(1, prop.multiProcessorCount) * (int)std::max<uint32_t>(1, envU32("RT_BLOCKS_PER_CU_NEAR", 2));
 	sc->maxBlocksPacketShadow = std::max(1, prop.multiProcessorCount) * (int)std::max<uint32_t>(1, envU32("RT_BLOCKS_PER_CU_SHADOW", 3));
@@ -1116,6 +1151,25 @@ int rt_intersect_batch(rt_scene* sc, const float* e, const float* d, size_t n, u
 	if (hit) HIPCHK(hipMemcpy(hit, dhit.p, n, hipMemcpyDeviceToHost));
 	if (obj_id) HIPCHK(hipMemcpy(obj_id, did.p, n * 4, hipMemcpyDeviceToHost));
 	if (t) HIPCHK(hipMemcpy(t, dt.p, n * 4, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_intersect_batch_static(rt_scene* sc, const float* e_dev, const float* d_dev, size_t n, uint8_t* hit_dev, int32_t* obj_id_dev, float* t_dev, void* stream) {
+	if (!sc || (n > 0 && (!e_dev || !d_dev))) { rt::set_error("rt_intersect_batch_static: bad argument"); return RT_EINVAL; }
+	if (n > RT_STATIC_MAX_RAYS) { rt::set_error("rt_intersect_batch_static: more than RT_STATIC_MAX_RAYS rays in one call (the scratch is a fixed device array; split the batch)"); return RT_ELIMIT; }
+	if (n == 0) return RT_OK;
+	sc->drain();   // frames in flight use the same traversal kernels' cursors only through their own lanes, but the call promises "after outstanding frames"
+	HIPCHK(hipSetDevice(sc->device));
+	StaticScratch* ws = sc->staticScratch;   // device address (hipGetSymbolAddress), never the array's name
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	const RtQueue rq{ ws->ray, RT_STATIC_MAX_RAYS }, hq{ ws->hit, RT_STATIC_MAX_RAYS };
+	// the array keeps the last call's contents: the work cursor and the queue counts must start at zero; the queue slots
+	// [0, n) are all rewritten by k_load_rays / k_intersect before they are read
+	HIPCHK(hipMemsetAsync(&ws->ctr, 0, sizeof(RtCounters), st));
+	rtk_load_rays(st, e_dev, d_dev, (uint32_t)n, 0, rq, 0);
+	rtk_intersect(st, sc->dev, sc->hasCsg, false, false, sc->maxBlocks, rq, (uint32_t)n, hq, &ws->ctr);
+	rtk_export_hits(st, sc->dev, hq, (uint32_t)n, hit_dev, obj_id_dev, t_dev);
+	HIPCHK(hipGetLastError());
 	return RT_OK;
 }
 

@@ -33,19 +33,22 @@ typedef rt_vec3 point3;
 typedef rt_vec3 colour3;
 #endif
 
+/* The two globals of raytracer.h:12-13, real objects exported by libraytracer_amd.so (csrc/host/raytracer_api.cpp defines
+ * `fov` as a double and `background_colour` as 12 bytes of three floats: the layout of glm::vec3 and of rt_vec3).  No macros:
+ * a caller may have members and locals called fov. */
+extern double fov;
+extern colour3 background_colour;
+
 extern "C" {
 /* exported by libraytracer_amd.so (csrc/host/raytracer_api.cpp) */
 void rtapi_choose_scene(const char* fn);
 int rtapi_trace(const float* e, const float* s, float* colour, int pick, int reflectionCount);
 int rtapi_shadow_ray(const float* point, const float* lightPos, float* shadow);
-double* rtapi_fov(void);
-float* rtapi_background_colour(void);
+double* rtapi_fov(void);                  /* &fov, for bindings that cannot name a data symbol */
+float* rtapi_background_colour(void);     /* &background_colour */
 rt_scene* rtapi_scene(void);
 const rt_flat_scene* rtapi_flat_scene(void);
 }
-
-#define fov (*rtapi_fov())
-#define background_colour (*reinterpret_cast<colour3*>(rtapi_background_colour()))
 
 inline void choose_scene(char const* fn) { rtapi_choose_scene(fn); }
 inline bool trace(const point3& e, const point3& s, colour3& colour, bool pick, int reflectionCount = 0) {

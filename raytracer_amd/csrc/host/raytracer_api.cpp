@@ -12,10 +12,16 @@
 #include <string>
 #include <vector>
 
+// raytracer.cpp:24-25: the two globals callers read (include/raytracer.h declares them `extern double fov; extern colour3
+// background_colour;` as raytracer.h:12-13 does; colour3 = glm::vec3 or rt_vec3, both three packed floats).  Namespace-scope
+// variables are not mangled, so these are the symbols `fov` and `background_colour`.
+struct rtapi_colour3 { float v[3]; };
+__attribute__((visibility("default"))) double fov = 60;
+__attribute__((visibility("default"))) rtapi_colour3 background_colour = { { 0, 0, 0 } };
+static_assert(sizeof(rtapi_colour3) == 12 && alignof(rtapi_colour3) == 4, "layout of glm::vec3");
+
 namespace {
 const char* PATH = "scenes/";   // raytracer.cpp:22
-double g_fov = 60;              // raytracer.cpp:24
-float g_background[3] = { 0, 0, 0 };
 rt_flat_scene* g_flat = nullptr;
 rt_scene* g_scene = nullptr;
 
@@ -23,8 +29,8 @@ rt_scene* g_scene = nullptr;
 
 extern "C" {
 
-double* rtapi_fov(void) { return &g_fov; }
-float* rtapi_background_colour(void) { return g_background; }
+double* rtapi_fov(void) { return &fov; }
+float* rtapi_background_colour(void) { return background_colour.v; }
 rt_scene* rtapi_scene(void) { return g_scene; }
 const rt_flat_scene* rtapi_flat_scene(void) { return g_flat; }
 
@@ -48,8 +54,8 @@ void rtapi_choose_scene(const char* fn) {
 	if (g_scene) rt_scene_free(g_scene);
 	if (g_flat) rt_flat_scene_free(g_flat);
 	g_flat = flat; g_scene = nullptr;
-	g_fov = flat->fov;
-	for (int i = 0; i < 3; i++) g_background[i] = flat->background[i];
+	fov = flat->fov;
+	for (int i = 0; i < 3; i++) background_colour.v[i] = flat->background[i];
 	const char* dev = getenv("RT_DEVICE");
 	rc = rt_scene_upload(flat, dev ? atoi(dev) : 0, &g_scene);
 	if (rc != RT_OK) {

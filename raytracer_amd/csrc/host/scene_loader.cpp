@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <future>
 #include <memory>
+#include <new>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -516,11 +517,15 @@ template <class T> static bool wr(FILE* f, const T* p, int64_t count) {
 	if (fwrite(&n, 8, 1, f) != 1) return false;
 	return n == 0 || (p && fwrite(p, sizeof(T), n, f) == n);
 }
-template <class T> static bool rd(FILE* f, std::vector<T>& v) {
+// One array of the file.  The count is not trusted: it must fit what is left of the file (a corrupt count must not turn
+// into a 64 GB resize) and, except for the texel bytes, the int32 counts of rt_flat_scene.
+template <class T> static bool rd(FILE* f, std::vector<T>& v, uint64_t& left, bool wide = false) {
 	uint64_t n = 0;
-	if (fread(&n, 8, 1, f) != 1) return false;
-	if (n > (1ull << 36) / sizeof(T)) return false;
+	if (left < 8 || fread(&n, 8, 1, f) != 1) return false;
+	left -= 8;
+	if (n > left / sizeof(T) || (!wide && n > 0x7fffffffull)) return false;
 	v.resize(n);
+	left -= n * sizeof(T);
 	return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
 }
 
@@ -548,18 +553,37 @@ int rt_flat_scene_load(const char* path, rt_flat_scene** out) {
 	*out = nullptr;
 	FILE* f = fopen(path, "rb");
 	if (!f) { rt::set_error(std::string("Unable to open scene file ") + path); return RT_EIO; }
-	auto* S = new rt::FlatSceneStore();
-	rt_flat_scene& V = S->view;
-	char magic[8];
-	bool ok = fread(magic, 8, 1, f) == 1 && !memcmp(magic, kMagic, 8) && fread(&V.fov, 8, 1, f) == 1 && fread(V.background, 12, 1, f) == 1 &&
-	          fread(&V.n_objects, 4, 1, f) == 1 && fread(V.root_box, 24, 1, f) == 1 && fread(&V.root_child, 4, 1, f) == 1 &&
-	          fread(&V.root_count, 4, 1, f) == 1;
-	ok = ok && rd(f, S->planes) && rd(f, S->spheres) && rd(f, S->tris) && rd(f, S->boxes) && rd(f, S->csgs) && rd(f, S->csg_nodes) &&
-	     rd(f, S->meshes) && rd(f, S->mesh_tris) && rd(f, S->uvs) && rd(f, S->materials) && rd(f, S->lights) && rd(f, S->textures) &&
-	     rd(f, S->texels) && rd(f, S->bvh_nodes) && rd(f, S->leaf_prims);
+	uint64_t left = 0;
+	if (fseek(f, 0, SEEK_END) == 0) { const long end = ftell(f); if (end > 0) left = (uint64_t)end; }
+	rewind(f);
+	const uint64_t header = 8 + 8 + 12 + 4 + 24 + 4 + 4;
+	rt::FlatSceneStore* S = nullptr;
+	bool ok = false;
+	try {   // nothing may escape an extern "C" entry point (std::bad_alloc from a resize would abort a ctypes caller)
+		S = new rt::FlatSceneStore();
+		rt_flat_scene& V = S->view;
+		char magic[8];
+		ok = left >= header && fread(magic, 8, 1, f) == 1 && !memcmp(magic, kMagic, 8) && fread(&V.fov, 8, 1, f) == 1 && fread(V.background, 12, 1, f) == 1 &&
+		     fread(&V.n_objects, 4, 1, f) == 1 && fread(V.root_box, 24, 1, f) == 1 && fread(&V.root_child, 4, 1, f) == 1 &&
+		     fread(&V.root_count, 4, 1, f) == 1;
+		left -= ok ? header : 0;
+		ok = ok && rd(f, S->planes, left) && rd(f, S->spheres, left) && rd(f, S->tris, left) && rd(f, S->boxes, left) && rd(f, S->csgs, left) &&
+		     rd(f, S->csg_nodes, left) && rd(f, S->meshes, left) && rd(f, S->mesh_tris, left) && rd(f, S->uvs, left) && rd(f, S->materials, left) &&
+		     rd(f, S->lights, left) && rd(f, S->textures, left) && rd(f, S->texels, left, true) && rd(f, S->bvh_nodes, left) && rd(f, S->leaf_prims, left);
+		if (ok) S->link();
+	} catch (const std::bad_alloc&) {
+		fclose(f);
+		delete S;
+		rt::set_error(std::string("out of memory reading ") + path);
+		return RT_ENOMEM;
+	} catch (const std::exception& e) {
+		fclose(f);
+		delete S;
+		rt::set_error(std::string("scene file: ") + e.what());
+		return RT_EPARSE;
+	}
 	fclose(f);
-	if (!ok) { delete S; rt::set_error(std::string("not a flat scene file or truncated: ") + path); return RT_EPARSE; }
-	S->link();
+	if (!ok) { delete S; rt::set_error(std::string("not a flat scene file, truncated, or with counts beyond the file's size: ") + path); return RT_EPARSE; }
 	*out = &S->view;
 	return RT_OK;
 }

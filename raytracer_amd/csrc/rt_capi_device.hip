@@ -26,6 +26,13 @@ namespace {
 #define RT_MAX_INFLIGHT 4
 #define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rt::set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); return RT_EHIP; } } while (0)
 
+// launch errors since the last look, with the kernel's name (rt_kernels.hip: noteLaunch), then anything else the runtime holds
+int launchesOk() {
+	if (const char* e = rtk_take_launch_error()) { rt::set_error(e); return RT_EHIP; }
+	HIPCHK(hipGetLastError());
+	return RT_OK;
+}
+
 uint32_t envU32(const char* name, uint32_t dflt) {
 	const char* v = getenv(name);
 	if (!v || !*v) return dflt;
@@ -554,7 +561,7 @@ struct Run {
 	bool coherent(int level) const { return src.camera && level < packetLevels; }
 
 	int syncCounters() {
-		HIPCHK(hipGetLastError());
+		if (int rcL = launchesOk()) return rcL;
 		HIPCHK(hipMemcpyAsync(ln->ctrHost, ln->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost, st));
 		HIPCHK(hipStreamSynchronize(st));
 		return RT_OK;
@@ -583,7 +590,7 @@ struct Run {
 			// the lane's stream never idles through a host round trip.
 			const bool early = coherent(level) && !timeK && !count && sc->areaLights.empty() && sc->nPointLights > 0 && sc->shadowRaysPerSurface > 0;
 			if (early) {
-				HIPCHK(hipGetLastError());
+				if (int rcL = launchesOk()) return rcL;
 				HIPCHK(hipMemcpyAsync(ln->ctrHost, ln->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost, st));
 				HIPCHK(hipEventRecord(ln->ev[4], st));
 				rtk_shadow_point(st, sc->dev, sc->hasCsg, false, true, sc->maxBlocksPacketShadow, ln->surfq, n, sc->pointLights, sc->nPointLights, sc->accum, aaSq, ln->ctr, true, sc->maxBlocksPacketShadow2);
@@ -658,6 +665,7 @@ int begin(rt_scene* sc, rt_scene::Lane* ln, hipStream_t st, uint32_t flags) {
 	return RT_OK;
 }
 int finish(rt_scene* sc, rt_scene::Lane* ln, hipStream_t st, Run& run, rt_stats* stats) {
+	if (int rcL = launchesOk()) return rcL;
 	HIPCHK(hipEventRecord(ln->ev[1], st));
 	if (run.flags & RT_FLAG_COUNTERS) HIPCHK(hipMemcpyAsync(ln->ctrHost, ln->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
@@ -718,7 +726,7 @@ int renderShard(rt_scene* sc, rt_scene::Job* job, int k) {
 	rtk_resolve(st, sc->accum, job->W, job->H, vr, vn, 0, (uint32_t)localPix, aaSq, 0, job->rgb);
 	// the padding slots of partial edge tiles went through the first level as inactive lanes: they are not rays
 	run.stats.rays_nearest -= (localPix - (uint64_t)ownedPixels(job->W, job->H, vr, vn)) * aaSq;
-	HIPCHK(hipGetLastError());
+	if (int rcL = launchesOk()) return rcL;
 	HIPCHK(hipEventRecord(job->evDone[k], st));
 	if (job->flags & (RT_FLAG_COUNTERS | RT_FLAG_TIME_KERNELS)) { if (int rc = finish(sc, ln, st, run, &job->part[k])) return rc; }
 	else job->part[k] = run.stats;
@@ -1169,7 +1177,7 @@ int rt_intersect_batch_static(rt_scene* sc, const float* e_dev, const float* d_d
 	rtk_load_rays(st, e_dev, d_dev, (uint32_t)n, 0, rq, 0);
 	rtk_intersect(st, sc->dev, sc->hasCsg, false, false, sc->maxBlocks, rq, (uint32_t)n, hq, &ws->ctr);
 	rtk_export_hits(st, sc->dev, hq, (uint32_t)n, hit_dev, obj_id_dev, t_dev);
-	HIPCHK(hipGetLastError());
+	if (int rcL = launchesOk()) return rcL;
 	return RT_OK;
 }
 
@@ -1209,7 +1217,7 @@ static int tilesCopy(rt_scene* sc, const float* src, float* dst, int width, int 
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	// enqueued, not waited for: between a rendered frame and its gather the host must stay free to submit the next frame
 	rtk_tiles_copy(st, src, dst, width, height, tile_rank, tile_ranks, (uint32_t)(localTiles(width, height, tile_rank, tile_ranks) * 256), mode);
-	HIPCHK(hipGetLastError());
+	if (int rcL = launchesOk()) return rcL;
 	return RT_OK;
 }
 int rt_tiles_pack(rt_scene* sc, const float* frame_dev, float* packed_dev, int width, int height, int tile_rank, int tile_ranks, void* stream) {

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "rt_scene.h"
+#include "csg_sort.h"
 
 namespace rtd {
 
@@ -351,6 +352,12 @@ __device__ __forceinline__ void csgLeafHits(const DevScene& S, const rt_csg_node
 	tf = csgLeafHit(S, nd, e, d, true, nullptr);
 }
 
+// std::sort of a list of more than 16 intervals (csg.cpp:199), kept out of line: no program of up to 16 sphere / box leaves gets here
+template <class At>
+__device__ __noinline__ void csgSortLong(At at, int n) {
+	csgSortStd<CsgIv>(at, n, [](const CsgIv& x, const CsgIv& y) { return x.a.t < y.a.t; });
+}
+
 // Evaluates the object's post-order program for one ray; returns csgObject::rayhit's t (0 = no hit) and the tag of
 // the selected boundary.  `cap` (intervals a list or the whole stack may hold) is either the full RTD_CSG_CAP or the
 // scene's own bound, which no step of any of its programs can exceed: the capacity checks below then never fire and
@@ -418,6 +425,8 @@ __device__ inline float csgEval(const DevScene& S, const rt_csg& c, f3 e, f3 d, 
 						out(n++) = v;
 					}
 				}
+				if (n > 16) csgSortLong(out, n);
+				else
 				for (int i = 1; i < n; i++) {
 					const CsgIv v = out(i);
 					int j = i;
@@ -467,7 +476,10 @@ __device__ inline float csgEval(const DevScene& S, const rt_csg& c, f3 e, f3 d, 
 						}
 					}
 				}
-				// std::sort by entry t; for <= 16 elements libstdc++ runs a plain (stable) insertion sort
+				// std::sort by entry t; for <= 16 elements libstdc++ runs a plain (stable) insertion sort, beyond that its introsort
+				// (csg_sort.h restates it: the order of equal entries is the library's)
+				if (n > 16) csgSortLong([&](int i) -> CsgIv& { return st.tmp(i); }, n);
+				else
 				for (int i = 1; i < n; i++) {
 					const CsgIv v = st.tmp(i);
 					int j = i;

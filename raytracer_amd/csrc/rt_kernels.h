@@ -109,6 +109,8 @@ struct RtAccum { unsigned long long* rgb; uint8_t* nonfinite; uint32_t npix; };
 
 using rtd::DevScene;
 
+// the first launch of the calling thread that failed since the last call, "launch of <kernel> failed: <hip error>", or null
+const char* rtk_take_launch_error();
 void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, int aaY, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq);
 void rtk_load_rays(hipStream_t st, const float* a, const float* b, uint32_t n, int bIsTarget, RtQueue rq, uint32_t pixBase);
 void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr);

@@ -1705,7 +1705,23 @@ inline unsigned gridPersistent(unsigned long long n, int maxBlocks) { return (un
 // =========================================================================================================
 // launch wrappers (host)
 // =========================================================================================================
-#define RT_LAUNCH(kernel, n, stream, ...) do { if ((n) > 0) hipLaunchKernelGGL(kernel, dim3(gridFor(n)), dim3(kBlock), 0, stream, __VA_ARGS__); } while (0)
+// Every launch is checked on the spot and the FIRST failure of the calling thread is kept with the kernel's name
+// (rtk_take_launch_error, read by the host loop where it next looks at errors): a bare hipGetLastError() at the next
+// synchronisation point would say "invalid configuration" without saying whose.
+static thread_local char g_launchError[320];
+static void noteLaunch(const char* kernel) {
+	const hipError_t e = hipGetLastError();
+	if (e != hipSuccess && !g_launchError[0]) snprintf(g_launchError, sizeof g_launchError, "launch of %s failed: %s", kernel, hipGetErrorString(e));
+}
+const char* rtk_take_launch_error() {
+	static thread_local char taken[320];
+	if (!g_launchError[0]) return nullptr;
+	snprintf(taken, sizeof taken, "%s", g_launchError);
+	g_launchError[0] = 0;
+	return taken;
+}
+#define RT_LAUNCH_RAW(kernel, grid, block, lds, stream, ...) do { hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__); noteLaunch(#kernel); } while (0)
+#define RT_LAUNCH(kernel, n, stream, ...) do { if ((n) > 0) RT_LAUNCH_RAW(kernel, dim3(gridFor(n)), dim3(kBlock), 0, stream, __VA_ARGS__); } while (0)
 // Persistent kernels start every wave on a statically numbered piece of work, so the grid must not exceed what is
 // resident at once (a workgroup that only starts when another has finished would sit on its piece until the end).
 static int computeUnits() {
@@ -1727,9 +1743,9 @@ template <class K> static int residentPerCU(K kernel, const char* name, size_t l
 }
 #define RT_LAUNCH_PS(kernel, n, maxBlocks, lds, stream, ...) do { if ((n) > 0) { \
 		const int _perCU = residentPerCU(kernel, #kernel, (size_t)(lds)); \
-		hipLaunchKernelGGL(kernel, dim3(gridPersistent(n, std::min(maxBlocks, _perCU * computeUnits()))), dim3(kBlock), (size_t)(lds), stream, __VA_ARGS__); } } while (0)
+		RT_LAUNCH_RAW(kernel, dim3(gridPersistent(n, std::min(maxBlocks, _perCU * computeUnits()))), dim3(kBlock), (size_t)(lds), stream, __VA_ARGS__); } } while (0)
 #define RT_LAUNCH_P(kernel, n, maxBlocks, stream, ...) RT_LAUNCH_PS(kernel, n, maxBlocks, 0, stream, __VA_ARGS__)
-#define RT_LAUNCH_S(kernel, n, lds, stream, ...) do { if ((n) > 0) hipLaunchKernelGGL(kernel, dim3(gridFor(n)), dim3(kBlock), lds, stream, __VA_ARGS__); } while (0)
+#define RT_LAUNCH_S(kernel, n, lds, stream, ...) do { if ((n) > 0) RT_LAUNCH_RAW(kernel, dim3(gridFor(n)), dim3(kBlock), lds, stream, __VA_ARGS__); } while (0)
 static size_t packetLdsBytes(const DevScene& S) { return (size_t)RT_PACKET_LDS_BYTES(S.treelet_levels, S.treelet_staging); }
 
 void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, int aaY, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq) {
@@ -1793,13 +1809,13 @@ void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint3
 	const size_t lds = RTD_CSG_LDS_BYTES(kTransmitBlock, S.csg_cap, S.csg_nodes_max);
 	static const bool noLds = getenv("RT_NO_CSG_LDS") != nullptr;
 	if (pick.ev) {   // rt_trace_pick: one ray tree, no need for the LDS lists
-		if (csg) hipLaunchKernelGGL((k_transmit<true, false, true>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
-		else hipLaunchKernelGGL((k_transmit<false, false, true>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
+		if (csg) RT_LAUNCH_RAW((k_transmit<true, false, true>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
+		else RT_LAUNCH_RAW((k_transmit<false, false, true>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
 		return;
 	}
-	if (!csg) hipLaunchKernelGGL((k_transmit<false, false, false>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
-	else if (lds <= 64u * 1024u && !noLds) hipLaunchKernelGGL((k_transmit<true, true, false>), grid, block, lds, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
-	else hipLaunchKernelGGL((k_transmit<true, false, false>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
+	if (!csg) RT_LAUNCH_RAW((k_transmit<false, false, false>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
+	else if (lds <= 64u * 1024u && !noLds) RT_LAUNCH_RAW((k_transmit<true, true, false>), grid, block, lds, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
+	else RT_LAUNCH_RAW((k_transmit<true, false, false>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
 }
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                       RtAccum A, uint32_t aaSq, RtCounters* ctr, bool countOnDevice, int maxBlocksPairs) {

@@ -9,9 +9,19 @@
 #include <cstdlib>
 #include <iostream>
 
+// a caller with names of its own called fov: a member, a local, and the flat scene's field (raytracer.h used to define fov as a macro)
+struct Lens { double fov; };
+static double widest(const Lens& a, const rt_flat_scene* flat) {
+	double fov = a.fov;
+	if (flat && flat->fov > fov) fov = flat->fov;
+	return fov;
+}
+
 int main(int argc, char** argv) {
 	if (argc < 4) return 2;
 	choose_scene(argv[1]);
+	if (widest(Lens{ 1.0 }, rtapi_flat_scene()) != ::fov || *rtapi_fov() != ::fov) return 3;
+	if (&rtapi_background_colour()[0] != &background_colour[0]) return 4;
 	const int W = atoi(argv[2]), H = atoi(argv[3]);
 	colour3 bg = background_colour;
 	printf("fov %.9g background %.9g %.9g %.9g\n", fov, bg[0], bg[1], bg[2]);

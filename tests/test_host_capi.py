@@ -129,6 +129,17 @@ def test_binary_scene_round_trip_and_corruption(flat_scenes, scene_dir, tmp_path
     (tmp_path / "magic.rtscene").write_bytes(b"NOTASCENE" + data[9:])
     with pytest.raises(rt.RtError):
         rt.FlatScene.load(str(tmp_path / "magic.rtscene"))
+    # element counts are not trusted: one that does not fit the rest of the file (here 2^35 planes, 2^31 planes) is a parse error,
+    # not a 64 GB allocation or an exception thrown through the C boundary
+    first_count = 8 + 8 + 12 + 4 + 24 + 4 + 4
+    import struct
+    for huge in (1 << 35, 1 << 31, (1 << 64) - 1):
+        bad = bytearray(data)
+        bad[first_count:first_count + 8] = struct.pack("<Q", huge)
+        (tmp_path / "count.rtscene").write_bytes(bad)
+        with pytest.raises(rt.RtError) as err:
+            rt.FlatScene.load(str(tmp_path / "count.rtscene"))
+        assert err.value.code == rt.capi.RT_EPARSE
 
 
 def test_moved_and_turned_cameras_match_the_reference():

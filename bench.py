@@ -8,9 +8,14 @@ A step is one frame of the C2 scene (100 352-triangle textured height field + tw
 directional + point light) at 1920x1080: generate -> intersect -> shade -> shadow -> resolve on the GPU, scene and
 queues resident in HBM, nothing crossing PCIe inside the timed region.  With N > 1 ranks the frame is sharded by
 interleaved 32x8 tiles (scene replicated per GPU), each rank packs its tiles and rank 0 gathers them over RCCL and
-unpacks them into the full frame -- that exchange is inside the timed region.  Scaling is WEAK: the sample grid
+unpacks them into the full frame -- that exchange is inside the timed region.  `value` scales WEAKLY: the sample grid
 grows with N (1x1, 2x1, 2x2, 4x2 samples per pixel for N = 1, 2, 4, 8) so every GPU traces one sample per pixel of
 its share, i.e. 1920*1080 primary rays per GPU at every N.
+
+With N > 1 the same run also times the multi-GPU configurations BASELINE.json names, STRONG-scaled (one frame of fixed size
+cut over the ranks, gather in the timed region), and reports them in `baseline_configs`: C4 (area lights, 64 shadow samples
+per hit, 1080p) for N = 2 .. 7 and C5 (4 999 122 triangles, 3840x2160, 4x4 samples per pixel) for N >= 8.
+`--all-configs` (N = 1) times every BASELINE configuration with a CPU baseline beside it (tools/bench_configs.py).
 
 Mrays = BVH::findNearest calls + BVH::calcShadow calls (the reference's own two ray queries, bvh.cpp:72,123).
 The JSON line also carries the roofline of the dominant kernel and the CPU restatement timed on this host.
@@ -29,8 +34,286 @@ sys.path.insert(0, ROOT)
 
 AA_GRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# Vector-instruction issue ceiling (MI355X_MICROARCH.md, cycle constants: a wave64 VALU instruction occupies its SIMD for 2 cycles):
+# 256 CUs x 4 SIMDs x 2.4 GHz / 2.  tools/ubench/valu_issue.hip measures 1.10e12 for v_mul_f32 and half that for packed f32 on the box.
+SIMDS, CLOCK_GHZ, VALU_ISSUE_CYCLES = 1024, 2.4, 2.0
+VALU_PEAK_GIPS = SIMDS * CLOCK_GHZ / VALU_ISSUE_CYCLES
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")
 # algorithmic bytes per unit of traversal work (with this build's 64 B two-child node)
-NODE_BYTES, TRI_BYTES, SPHERE_BYTES, RAY_QUEUE_BYTES, HIT_QUEUE_BYTES, SURF_BYTES = 64, 64, 32, 44, 12, 84
+NODE_BYTES, TRI_BYTES, RAY_QUEUE_BYTES, HIT_QUEUE_BYTES, SURF_BYTES = 64, 64, 44, 12, 84
+
+
+class Workload:
+    def __init__(self, name, label, flat, W, H, aa, max_depth, eye=(0.0, 0.0, 0.0), rot_x=0.0):
+        self.name, self.label, self.flat, self.W, self.H, self.aa, self.max_depth, self.eye, self.rot_x = name, label, flat, W, H, aa, max_depth, eye, rot_x
+
+
+def make_workload(kind, args, world, rt, scenes, tmp):
+    if kind == "c2":
+        flat = rt.FlatScene.from_json(scenes.c2_scene(tmp, grid=args.grid))
+        ax, ay = AA_GRID.get(world, (world, 1))
+        return Workload("C2", f"C2: {flat.info.n_tris}-triangle textured height field + 2 bump spheres, ambient+directional+point light, "
+                        f"{args.width}x{args.height}, {ax}x{ay} samples/pixel, tiles sharded over {world} GPU(s)",
+                        flat, args.width, args.height, (ax, ay), rt.MAX_REFLECTIONS, (0.0, 1.5, 1.0), -0.3)
+    if kind == "c4":
+        flat = rt.FlatScene.from_json(scenes.c4_scene(tmp, args.c4_samples))
+        return Workload("C4", f"C4: scene m's geometry with two area lights of {args.c4_samples} samples each, {args.width}x{args.height}, 1 sample/pixel, "
+                        f"one frame strong-scaled over {world} GPU(s)", flat, args.width, args.height, (1, 1), rt.MAX_REFLECTIONS)
+    if kind == "c5":
+        flat = rt.FlatScene.from_json(scenes.c5_scene(tmp, args.c5_grid))
+        W, H = 2 * args.width, 2 * args.height
+        return Workload("C5", f"C5: {flat.info.n_tris}-triangle height field, directional + point light, {W}x{H}, 4x4 samples/pixel, "
+                        f"one frame strong-scaled over {world} GPU(s)", flat, W, H, (4, 4), rt.MAX_REFLECTIONS, (0.0, 1.5, 1.0), -0.3)
+    raise ValueError(kind)
+
+
+class Runner:
+    """One workload on this rank's GPU: frames in flight, and with several ranks the tile exchange to rank 0."""
+
+    def __init__(self, ctx, wl, D, rgb8=False):
+        self.ctx, self.wl, self.rgb8 = ctx, wl, rgb8
+        rt, torch = ctx.rt, ctx.torch
+        self.scene = rt.Scene(wl.flat, ctx.local_rank)
+        self.cam = rt.Camera(wl.flat.fov, wl.W, wl.H, eye=wl.eye, rot_x=wl.rot_x)
+        self.D = D
+        dev, W, H, world, rank = ctx.dev, wl.W, wl.H, ctx.world, ctx.rank
+        self.frames = [torch.zeros(H, W, 3, device=dev, dtype=torch.float32) for _ in range(D)]
+        self.stream = torch.cuda.current_stream(dev).cuda_stream
+        # gather payload: every rank's buffer padded to the largest tile count (8100 tiles do not divide by 8), so that the
+        # exchange is ONE grouped gather -- all peers send to the root at once, each over its own xGMI link -- instead of a
+        # chain of point-to-point receives.  float RGB (12 B per pixel) or, with --rgb8, bytes quantised on the device (3 B).
+        self.pad = max(self.scene.tiles_count(W, H, r, world) for r in range(world)) * 256 * 3
+        pdt = torch.uint8 if rgb8 else torch.float32
+        self.packed = torch.zeros(self.pad, device=dev, dtype=pdt)
+        self.sizes = [self.pad] * world
+        self.recv = [torch.zeros(self.pad, device=dev, dtype=pdt) for _ in range(world)] if (world > 1 and rank == 0) else None
+        self.frame8 = torch.zeros(H, W, 3, device=dev, dtype=torch.uint8) if (rgb8 and rank == 0) else None
+        # The exchange runs on a stream of its own.  Lane 0 of the renderer works on the caller's stream (torch's current one):
+        # a gather queued there would hold that lane's next shards back until every rank had arrived.  Order is kept with two
+        # events per frame buffer: the side stream starts after the frame is complete (rt_render_wait has waited for it on the
+        # host), and the next frame rendered into the same buffer starts after that buffer's tiles were packed and unpacked.
+        self.side = torch.cuda.Stream(device=dev) if world > 1 else None
+        self.assembled = [None] * D
+
+    def close(self):
+        self.scene.close()
+
+    def assemble(self, slot):
+        # tiles -> rank 0 (one grouped RCCL gather over xGMI, every peer sending to the root at once), then de-interleave
+        ctx, wl, sc = self.ctx, self.wl, self.scene
+        torch, W, H, rank, world = ctx.torch, wl.W, wl.H, ctx.rank, ctx.world
+        buf = self.frames[slot]
+        with torch.cuda.stream(self.side):
+            ss = self.side.cuda_stream
+            if self.rgb8:
+                sc.tiles_pack_rgb8(buf.data_ptr(), self.packed.data_ptr(), W, H, rank, world, stream=ss)
+            else:
+                sc.tiles_pack(buf.data_ptr(), self.packed.data_ptr(), W, H, rank, world, stream=ss)
+            if ctx.rehearsal:
+                host = ctx.rd.gather_packed(self.packed.cpu(), self.sizes, rank, world)
+                bufs = [h.to(ctx.dev) for h in host] if rank == 0 else None
+            else:
+                bufs = ctx.rd.gather_packed(self.packed, self.sizes, rank, world, bufs=self.recv)
+            if rank == 0:
+                if self.rgb8:
+                    sc.tiles_quantize_rgb8(buf.data_ptr(), self.frame8.data_ptr(), W, H, 0, world, stream=ss)
+                for r in range(1, world):
+                    if self.rgb8:
+                        sc.tiles_unpack_rgb8(bufs[r].data_ptr(), self.frame8.data_ptr(), W, H, r, world, stream=ss)
+                    else:
+                        sc.tiles_unpack(bufs[r].data_ptr(), buf.data_ptr(), W, H, r, world, stream=ss)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self.assembled[slot] = ev
+
+    def buffer_free(self, slot):
+        """The caller's stream (and with it the frame about to be submitted) waits until the buffer's last exchange is through."""
+        if self.assembled[slot] is not None:
+            self.ctx.torch.cuda.current_stream(self.ctx.dev).wait_event(self.assembled[slot])
+            self.assembled[slot] = None
+
+    def step(self, flags=0, max_depth=None):
+        """One synchronous frame."""
+        wl, ctx = self.wl, self.ctx
+        self.buffer_free(0)
+        st = self.scene.render_into(self.frames[0].data_ptr(), wl.W, wl.H, aa=wl.aa, camera=self.cam, tile_rank=ctx.rank, tile_ranks=ctx.world, stream=self.stream,
+                                    flags=flags, max_depth=wl.max_depth if max_depth is None else max_depth)
+        if ctx.world > 1:
+            self.assemble(0)
+            self.side.synchronize()
+        return st
+
+    def run_steps(self, k):
+        """k frames with up to D in flight: frame i+1 is queued before frame i is waited for (and, with N > 1 ranks, gathered)."""
+        wl, ctx, sc = self.wl, self.ctx, self.scene
+        rays, pending = 0, []
+
+        def retire():
+            nonlocal rays
+            ticket, slot = pending.pop(0)
+            st = sc.render_wait(ticket)
+            if ctx.world > 1:
+                self.assemble(slot)
+            rays += st["rays_nearest"] + st["rays_shadow"]
+        for i in range(k):
+            if len(pending) == self.D:
+                retire()
+            slot = i % self.D
+            self.buffer_free(slot)
+            pending.append((sc.render_submit(self.frames[slot].data_ptr(), wl.W, wl.H, aa=wl.aa, camera=self.cam, tile_rank=ctx.rank, tile_ranks=ctx.world,
+                                             stream=self.stream, max_depth=wl.max_depth), slot))
+        while pending:
+            retire()
+        return rays
+
+    def timed(self, steps, warmup):
+        """(seconds for `steps` frames -- max over ranks --, rays of the whole job, latency of a frame rendered alone in ms)"""
+        ctx = self.ctx
+        self.run_steps(warmup)
+        ctx.barrier()
+        t0 = time.perf_counter()
+        rays = self.run_steps(steps)
+        ctx.barrier()
+        elapsed = time.perf_counter() - t0
+        ctx.barrier()
+        t1 = time.perf_counter()
+        reps = 5 if elapsed / max(steps, 1) < 0.02 else 2
+        for _ in range(reps):
+            self.step()
+        ctx.barrier()
+        latency_ms = (time.perf_counter() - t1) / reps * 1e3
+        return ctx.max_over_ranks(elapsed), ctx.sum_over_ranks(rays), latency_ms
+
+    def assembled_equals_single_rank(self):
+        """Outside the timed region: the frame assembled from every rank's tiles must be, bit for bit, the frame one rank renders alone
+        (with --rgb8: its 8-bit form as rt_quantize_rgb8 makes it)."""
+        ctx, wl, torch = self.ctx, self.wl, self.ctx.torch
+        if ctx.world == 1:
+            return None
+        ok = None
+        self.step()
+        if ctx.rank == 0:
+            alone = torch.zeros(wl.H, wl.W, 3, device=ctx.dev, dtype=torch.float32)
+            self.scene.render_into(alone.data_ptr(), wl.W, wl.H, aa=wl.aa, camera=self.cam, tile_rank=0, tile_ranks=1, stream=self.stream, max_depth=wl.max_depth)
+            if self.rgb8:
+                want = torch.from_numpy(ctx.rt.quantize_rgb8(alone.cpu().numpy()))
+                ok = bool(torch.equal(want, self.frame8.cpu()))
+            else:
+                ok = bool(torch.equal(alone.view(torch.int32), self.frames[0].view(torch.int32)))
+            del alone
+        ctx.barrier()
+        return ok
+
+
+class Ctx:
+    pass
+
+
+def load_pmc():
+    """Counters of the final build's kernels (tools/pmc_r02.sh -> tools/pmc_summary.py): they cannot be read from inside this process,
+    so they come from the committed file -- and only if it was taken with these very sources."""
+    from raytracer_amd import buildinfo
+    try:
+        with open(PMC_FILE) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        return None, "no counter file"
+    if pmc.get("source_sha") != buildinfo.source_sha():
+        return None, f"counter file is for sources {pmc.get('source_sha')}, this build is {buildinfo.source_sha()}"
+    return pmc, None
+
+
+def roofline_block(runner, flat):
+    """Roofline of the dominant kernel.  The two traversal kernels of level 0 (primary rays and their shadow rays: the packet
+    kernels) carry the frame.  They are isolated by rendering with max_depth 0 -- level 0 launches exactly the same two kernels
+    on exactly the same rays whatever the depth limit -- so each hipEvent bracket is ONE launch of ONE kernel, timed live on the
+    stream it runs on.  What binds them is vector-instruction issue, not memory (the scene is cache-resident and a packet
+    fetches a node once for 64 rays): achieved = VALU wave-instructions per launch (SQ_INSTS_VALU of the committed counter pass
+    of this build) / the live launch time, peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction."""
+    import raytracer_amd as rt
+    timed_all = [runner.step(flags=rt.RT_FLAG_TIME_KERNELS, max_depth=0) for _ in range(5)]
+    counted = runner.step(flags=rt.RT_FLAG_COUNTERS, max_depth=0)
+    full = runner.step(flags=rt.RT_FLAG_TIME_KERNELS)
+    runner.ctx.barrier()
+    if runner.ctx.rank != 0:
+        return None
+    near_ms = float(np.mean([t["nearest_ms"] for t in timed_all[1:]]))
+    shad_ms = float(np.mean([t["shadow_ms"] for t in timed_all[1:]]))
+    near_bytes = (counted["nodes_nearest"] * NODE_BYTES + counted["prims_nearest"] * TRI_BYTES + counted["rays_nearest"] * (RAY_QUEUE_BYTES + HIT_QUEUE_BYTES))
+    shad_bytes = (counted["nodes_shadow"] * NODE_BYTES + counted["prims_shadow"] * TRI_BYTES + counted["rays_shadow"] * SURF_BYTES)
+    pmc, why = load_pmc()
+    kernels = (pmc or {}).get("kernels", {})
+    # the kernel names of this build's level-0 launches come with the counter file (the fused and the queued forms differ)
+    near_name = (pmc or {}).get("nearest_kernel", "k_intersect_packet")
+    shad_name = (pmc or {}).get("shadow_kernel", "k_shadow_point_packet2")
+    if shad_ms >= near_ms:
+        kname, ms, alg_bytes, rays = shad_name, shad_ms, shad_bytes, counted["rays_shadow"]
+        busy = counted["nodes_shadow"] / max(1, 64 * counted["steps_shadow"])
+    else:
+        kname, ms, alg_bytes, rays = near_name, near_ms, near_bytes, counted["rays_nearest"]
+        busy = counted["nodes_nearest"] / max(1, 64 * counted["steps_nearest"])
+    k = kernels.get(kname)
+    out = {"bound": "valu_issue", "kernel": kname, "achieved": None, "peak": round(VALU_PEAK_GIPS, 1), "unit": "G wave-instr/s", "frac": None,
+           "traffic": None, "hbm_frac": None, "launch_ms": round(ms, 4), "launches_per_step": 1,
+           "peak_is": f"{SIMDS} SIMDs x {CLOCK_GHZ} GHz / {VALU_ISSUE_CYCLES:g} cycles per wave64 VALU instruction"}
+    if k:
+        valu = k["SQ_INSTS_VALU"]
+        achieved = valu / (ms * 1e-3) / 1e9
+        traffic = k.get("traffic_bytes_per_launch")
+        wc = k.get("SQ_WAVE_CYCLES")
+        out.update({"achieved": round(achieved, 1), "frac": round(achieved / VALU_PEAK_GIPS, 4),
+                    "valu_insts_per_launch": int(valu), "valu_insts_per_ray": round(valu / max(1, rays), 2),
+                    "salu_insts_per_launch": int(k.get("SQ_INSTS_SALU", 0)),
+                    # share of a wave's resident time parked in s_waitcnt / at barriers, stalled at issue, and issuing (quad-cycle counters, disjoint)
+                    "wave_wait_frac": round(k["SQ_WAIT_ANY"] / wc, 3) if wc else None,
+                    "wave_issue_stall_frac": round(k["SQ_WAIT_INST_ANY"] / wc, 3) if wc else None,
+                    "wave_active_frac": round(k["SQ_ACTIVE_INST_ANY"] / wc, 3) if wc else None,
+                    "counter_launch_ms": round(k["GRBM_GUI_ACTIVE"] / 8 / (CLOCK_GHZ * 1e6), 4) if k.get("GRBM_GUI_ACTIVE") else None,
+                    "traffic": traffic,
+                    "hbm_achieved_gbs": round(traffic / (ms * 1e-3) / 1e9, 1) if traffic else None,
+                    "hbm_frac": round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "counters_from": os.path.relpath(PMC_FILE, ROOT)})
+        # the whole step against the same two ceilings: every kernel's instructions and HBM bytes over the pipelined frame time
+        out["_step_valu"] = sum(v.get("SQ_INSTS_VALU", 0) * v.get("launches_per_frame", 1) for v in kernels.values())
+        out["_step_traffic"] = sum((v.get("traffic_bytes_per_launch") or 0) * v.get("launches_per_frame", 1) for v in kernels.values())
+    else:
+        out["counters_missing"] = why or f"{kname} is not in the counter file"
+    out.update({"busy_lane_frac": round(busy, 3),
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+                "algorithmic_bytes_note": "per-RAY bytes of SURVEY 8d (64 B x nodes + 64 B x triangle tests + queue records); a packet fetches a node once for 64 rays "
+                                          "from LDS, so these are not HBM bytes and no fraction is taken of them",
+                "nearest_ms": round(near_ms, 4), "shadow_ms": round(shad_ms, 4),
+                "all_levels_nearest_ms": round(full["nearest_ms"], 4), "all_levels_shadow_ms": round(full["shadow_ms"], 4), "levels": int(full["levels"]),
+                "nodes_per_ray_nearest": round(counted["nodes_nearest"] / max(1, counted["rays_nearest"]), 2),
+                "nodes_per_ray_shadow": round(counted["nodes_shadow"] / max(1, counted["rays_shadow"]), 2),
+                "prims_per_ray_nearest": round(counted["prims_nearest"] / max(1, counted["rays_nearest"]), 2),
+                "prims_per_ray_shadow": round(counted["prims_shadow"] / max(1, counted["rays_shadow"]), 2),
+                "steps_per_packet_nearest": round(counted["steps_nearest"] / max(1, counted["rays_nearest"] / 64), 1),
+                "steps_per_packet_shadow": round(counted["steps_shadow"] / max(1, counted["rays_shadow"] / 64), 1),
+                "spheres": int(flat.info.n_spheres)})
+    return out
+
+
+def cpu_baseline_block(rt, wl, seconds=10.0):
+    """The oracle restatement (bit-identical to the compiled reference on the bundled scenes) on this host's cores: same scene and
+    camera at a quarter of the resolution per axis, one thread once and all threads for ~10 s."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    cw, ch = wl.W // 4, wl.H // 4
+    ccam = rt.Camera(wl.flat.fov, cw, ch, eye=wl.eye, rot_x=wl.rot_x)
+    threads = min(16, os.cpu_count() or 1)
+    t1 = time.perf_counter()
+    _, n1, s1 = oracle.render(wl.flat, ccam, cw, ch, seed=1, threads=1)
+    d1 = time.perf_counter() - t1
+    reps, tot, t2 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t2 < seconds:
+        _, nn, ns = oracle.render(wl.flat, ccam, cw, ch, seed=1, threads=threads)
+        tot += nn + ns
+        reps += 1
+    dN = time.perf_counter() - t2
+    return {"value": round(tot / dN / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"same C2 scene and camera at {cw}x{ch} (1/16 of the pixels), full ray tree, {reps} frames in {dN:.1f} s on {threads} threads",
+            "single_thread_value": round((n1 + s1) / d1 / 1e6, 3)}
 
 
 def main():
@@ -42,7 +325,14 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--grid", type=int, default=224, help="height-field cells per side (224 -> 100 352 triangles)")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight (rt_render_submit / rt_render_wait); 1 = one synchronous frame at a time")
+    ap.add_argument("--rgb8", action="store_true", help="N > 1: quantise to 8-bit pixels on the device before the gather (3 B instead of 12 B per pixel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel timing / counting passes (counter runs under rocprofv3)")
+    ap.add_argument("--no-baseline-configs", action="store_true", help="N > 1: skip the strong-scaled C4 / C5 frames")
+    ap.add_argument("--c4-samples", type=int, default=64)
+    ap.add_argument("--c5-grid", type=int, default=1581, help="C5 height-field cells per side (1581 -> 4 999 122 triangles)")
+    ap.add_argument("--config-steps", type=int, default=10, help="timed frames of the C4 / C5 runs")
+    ap.add_argument("--all-configs", action="store_true", help="N = 1: also time every BASELINE configuration with a CPU baseline (tools/bench_configs.py -> profiles/r02_configs.json)")
     ap.add_argument("--save", default=None, help="write the last frame as a BMP (rank 0)")
     args = ap.parse_args()
 
@@ -52,13 +342,16 @@ def main():
     from raytracer_amd import scenes
     from raytracer_amd import distributed as rd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    ctx = Ctx()
+    ctx.rt, ctx.torch, ctx.dist, ctx.rd = rt, torch, dist, rd
+    ctx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.rank = rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal on a one-GPU box: RT_BENCH_REHEARSAL=1 puts every rank on device 0 and gathers through the host over gloo
-    rehearsal = os.environ.get("RT_BENCH_REHEARSAL") == "1"
+    ctx.rehearsal = rehearsal = os.environ.get("RT_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    ctx.local_rank = local_rank
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -73,208 +366,111 @@ def main():
         args.gpus = world
     if rt.device_count() < 1:
         raise RuntimeError("bench.py needs a HIP device: the trace path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    ctx.dev = dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-
-    W, H = args.width, args.height
-    ax, ay = AA_GRID.get(world, (world, 1))
-    eye, rot_x = (0.0, 1.5, 1.0), -0.3
-
-    # scene: generated deterministically in the reference's JSON schema, loaded by the library's choose_scene restatement
-    with tempfile.TemporaryDirectory() as tmp:
-        path = scenes.c2_scene(tmp, grid=args.grid)
-        flat = rt.FlatScene.from_json(path)
-    scene = rt.Scene(flat, local_rank)
-    cam = rt.Camera(flat.fov, W, H, eye=eye, rot_x=rot_x)
-
-    D = max(1, min(3, args.inflight))
-    frames = [torch.zeros(H, W, 3, device=dev, dtype=torch.float32) for _ in range(D)]
-    frame = frames[0]
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    # gather payload: every rank's buffer padded to the largest tile count (8100 tiles do not divide by 8), so that the
-    # exchange is ONE grouped gather -- all peers send to the root at once, each over its own xGMI link -- instead of a
-    # chain of point-to-point receives
-    pad = max(scene.tiles_count(W, H, r, world) for r in range(world)) * 256 * 3
-    packed = torch.zeros(pad, device=dev, dtype=torch.float32)
-    sizes = [pad] * world
-    recv = [torch.zeros(n, device=dev, dtype=torch.float32) for n in sizes] if (world > 1 and rank == 0) else None
-
-    # The exchange runs on a stream of its own.  Lane 0 of the renderer works on the caller's stream (torch's current one):
-    # a gather queued there would hold that lane's next shards back until every rank had arrived.  Order is kept with two
-    # events per frame buffer: the side stream starts after the frame is complete (rt_render_wait has waited for it on the
-    # host), and the next frame rendered into the same buffer starts after that buffer's tiles were packed and unpacked.
-    side = torch.cuda.Stream(device=dev) if world > 1 else None
-    assembled = [None] * D
-
-    def assemble(slot):
-        # tiles -> rank 0 (one grouped RCCL gather over xGMI, every peer sending to the root at once), then de-interleave
-        buf = frames[slot]
-        with torch.cuda.stream(side):
-            scene.tiles_pack(buf.data_ptr(), packed.data_ptr(), W, H, rank, world, stream=side.cuda_stream)
-            if rehearsal:
-                host = rd.gather_packed(packed.cpu(), sizes, rank, world)
-                bufs = [h.to(dev) for h in host] if rank == 0 else None
-            else:
-                bufs = rd.gather_packed(packed, sizes, rank, world, bufs=recv)
-            if rank == 0:
-                for r in range(1, world):
-                    scene.tiles_unpack(bufs[r].data_ptr(), buf.data_ptr(), W, H, r, world, stream=side.cuda_stream)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        assembled[slot] = ev
-
-    def buffer_free(slot):
-        """The caller's stream (and with it the frame about to be submitted) waits until the buffer's last exchange is through."""
-        if assembled[slot] is not None:
-            torch.cuda.current_stream(dev).wait_event(assembled[slot])
-            assembled[slot] = None
-
-    def step(flags=0, max_depth=rt.MAX_REFLECTIONS):
-        """One synchronous frame."""
-        buffer_free(0)
-        st = scene.render_into(frame.data_ptr(), W, H, aa=(ax, ay), camera=cam, tile_rank=rank, tile_ranks=world, stream=stream, flags=flags,
-                               max_depth=max_depth)
-        if world > 1:
-            assemble(0)
-            side.synchronize()
-        return st
-
-    def run_steps(k):
-        """k frames with up to D in flight: frame i+1 is queued before frame i is waited for (and, with N > 1 ranks, gathered)."""
-        rays, pending = 0, []
-        def retire():
-            nonlocal rays
-            ticket, slot = pending.pop(0)
-            st = scene.render_wait(ticket)
-            if world > 1:
-                assemble(slot)
-            rays += st["rays_nearest"] + st["rays_shadow"]
-        for i in range(k):
-            if len(pending) == D:
-                retire()
-            slot = i % D
-            buffer_free(slot)
-            pending.append((scene.render_submit(frames[slot].data_ptr(), W, H, aa=(ax, ay), camera=cam, tile_rank=rank, tile_ranks=world, stream=stream), slot))
-        while pending:
-            retire()
-        return rays
+    cdev = "cpu" if rehearsal else dev
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    run_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    rays = run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # latency of a frame rendered alone (nothing else in flight), for the record
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(5):
-        step()
-    barrier()
-    latency_ms = (time.perf_counter() - t1) / 5 * 1e3
-    # outside the timed region: the frame assembled from every rank's tiles must be, bit for bit, the frame one rank renders alone
-    assembled_ok = None
-    if world > 1:
-        if rank == 0:
-            alone = torch.zeros(H, W, 3, device=dev, dtype=torch.float32)
-            scene.render_into(alone.data_ptr(), W, H, aa=(ax, ay), camera=cam, tile_rank=0, tile_ranks=1, stream=stream)
-            assembled_ok = bool(torch.equal(alone.view(torch.int32), frame.view(torch.int32)))
-            del alone
-        barrier()
-    if world > 1:
-        cdev = "cpu" if rehearsal else dev
-        tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        rr = torch.tensor([rays], device=cdev, dtype=torch.int64)
-        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
-        rays = int(rr.item())
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], device=cdev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # ---- roofline of the dominant kernel: live hipEvent timing of the traversal launches + an untimed counting pass ----
-    # The two traversal kernels of level 0 (primary rays and their shadow rays: the packet kernels) carry the frame.
-    # They are isolated by rendering with max_depth 0 -- level 0 launches exactly the same two kernels on exactly the
-    # same rays whatever the depth limit -- so each hipEvent bracket below is ONE launch of ONE kernel.
-    timed_all = [step(flags=rt.RT_FLAG_TIME_KERNELS, max_depth=0) for _ in range(5)]
-    counted = step(flags=rt.RT_FLAG_COUNTERS, max_depth=0)
-    full = step(flags=rt.RT_FLAG_TIME_KERNELS)
-    barrier()
-    roofline = None
-    if rank == 0:
-        near_ms = float(np.mean([t["nearest_ms"] for t in timed_all[1:]]))
-        shad_ms = float(np.mean([t["shadow_ms"] for t in timed_all[1:]]))
-        n_sph = flat.info.n_spheres
-        # algorithmic bytes: nodes read, primitive records tested, queue records read and written (SURVEY.md 8d)
-        near_bytes = (counted["nodes_nearest"] * NODE_BYTES + counted["prims_nearest"] * TRI_BYTES +
-                      counted["rays_nearest"] * (RAY_QUEUE_BYTES + HIT_QUEUE_BYTES))
-        shad_bytes = (counted["nodes_shadow"] * NODE_BYTES + counted["prims_shadow"] * TRI_BYTES + counted["rays_shadow"] * SURF_BYTES)
-        if shad_ms >= near_ms:
-            # two point-type lights: the two-rays-per-lane form of the shadow packet kernel
-            kname, ms, nbytes = "k_shadow_point_packet2", shad_ms, shad_bytes
-        else:
-            kname, ms, nbytes = "k_intersect_packet", near_ms, near_bytes
-        achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        # HBM-side bytes per launch of that kernel from the PMC passes (tools/pmc_passes.sh -> profiles/r01_traffic.json:
-        # FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes); counters cannot be read from inside this process
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                traffic = json.load(f).get(kname, {}).get("traffic_bytes_per_launch")
-        except (OSError, ValueError):
-            pass
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "launch_ms": round(ms, 4), "launches_per_step": 1,
-                    "algorithmic_bytes_per_launch": int(nbytes),
-                    "nearest_ms": round(near_ms, 4), "shadow_ms": round(shad_ms, 4),
-                    "all_levels_nearest_ms": round(full["nearest_ms"], 4), "all_levels_shadow_ms": round(full["shadow_ms"], 4),
-                    "levels": int(full["levels"]),
-                    "nodes_per_ray_nearest": round(counted["nodes_nearest"] / max(1, counted["rays_nearest"]), 2),
-                    "nodes_per_ray_shadow": round(counted["nodes_shadow"] / max(1, counted["rays_shadow"]), 2),
-                    "prims_per_ray_nearest": round(counted["prims_nearest"] / max(1, counted["rays_nearest"]), 2),
-                    "prims_per_ray_shadow": round(counted["prims_shadow"] / max(1, counted["rays_shadow"]), 2),
-                    "spheres": int(n_sph)}
+    def sum_over_ranks(n):
+        if world == 1:
+            return n
+        t = torch.tensor([n], device=cdev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
+    ctx.barrier, ctx.max_over_ranks, ctx.sum_over_ranks = barrier, max_over_ranks, sum_over_ranks
 
-    # ---- CPU baseline: the oracle restatement (bit-identical to the compiled reference on the bundled scenes) ----
+    D = max(1, min(3, args.inflight))
+    # ---- the metric's workload: C2, generated deterministically in the reference's JSON schema, loaded by the library's choose_scene restatement ----
+    with tempfile.TemporaryDirectory() as tmp:
+        wl = make_workload("c2", args, world, rt, scenes, tmp)
+    runner = Runner(ctx, wl, D, rgb8=args.rgb8)
+    elapsed, rays, latency_ms = runner.timed(args.steps, args.warmup)
+    assembled_ok = runner.assembled_equals_single_rank()
+    roofline = None if args.no_roofline else roofline_block(runner, wl.flat)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle
-        cw, ch = W // 4, H // 4
-        ccam = rt.Camera(flat.fov, cw, ch, eye=eye, rot_x=rot_x)
-        threads = min(16, os.cpu_count() or 1)
-        t1 = time.perf_counter()
-        _, n1, s1 = oracle.render(flat, ccam, cw, ch, seed=1, threads=1)
-        d1 = time.perf_counter() - t1
-        reps, tot, t2 = 0, 0, time.perf_counter()
-        while time.perf_counter() - t2 < 10.0:
-            _, nn, ns = oracle.render(flat, ccam, cw, ch, seed=1, threads=threads)
-            tot += nn + ns
-            reps += 1
-        dN = time.perf_counter() - t2
-        cpu = {"value": round(tot / dN / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-               "sample": f"same C2 scene and camera at {cw}x{ch} (1/16 of the pixels), full ray tree, {reps} frames in {dN:.1f} s on {threads} threads",
-               "single_thread_value": round((n1 + s1) / d1 / 1e6, 3)}
+        cpu = cpu_baseline_block(rt, wl)
+    if rank == 0 and args.save:
+        rt.write_bmp(args.save, runner.frames[(args.steps - 1) % D].cpu().numpy())
+    runner.close()
+    del runner
+
+    # ---- N > 1: the multi-GPU configurations BASELINE.json names, one frame strong-scaled over the ranks ----
+    extra = None
+    if world > 1 and not args.no_baseline_configs:
+        kind = "c5" if world >= 8 else "c4"
+        try:
+            with tempfile.TemporaryDirectory() as tmp:
+                wl2 = make_workload(kind, args, world, rt, scenes, tmp)
+            r2 = Runner(ctx, wl2, D, rgb8=args.rgb8)
+            e2, rays2, lat2 = r2.timed(args.config_steps, 2)
+            ok2 = r2.assembled_equals_single_rank()
+            # the same frame on rank 0 alone, for the strong-scaling ratio (the other ranks wait at the barrier)
+            alone_ms = None
+            if rank == 0:
+                world_saved, rank_saved = ctx.world, ctx.rank
+                ctx.world = 1
+                try:
+                    solo = Runner(ctx, wl2, D)
+                    solo.run_steps(1)
+                    torch.cuda.synchronize(dev)
+                    n_solo = max(2, args.config_steps // 2)
+                    t0 = time.perf_counter()
+                    solo.run_steps(n_solo)
+                    torch.cuda.synchronize(dev)
+                    alone_ms = (time.perf_counter() - t0) / n_solo * 1e3
+                    solo.close()
+                finally:
+                    ctx.world, ctx.rank = world_saved, rank_saved
+            barrier()
+            r2.close()
+            ms2 = e2 / args.config_steps * 1e3
+            extra = {wl2.name: {"workload": wl2.label, "scaling": "strong", "n_gpus": world, "steps": args.config_steps,
+                                "ms_per_frame": round(ms2, 4), "value": round(rays2 / e2 / 1e6, 2), "unit": "Mrays/s",
+                                "rays_per_frame": rays2 // args.config_steps, "single_frame_latency_ms": round(lat2, 4),
+                                "one_gpu_ms_per_frame": None if alone_ms is None else round(alone_ms, 4),
+                                "speedup_over_one_gpu": None if alone_ms is None else round(alone_ms / ms2, 3),
+                                "assembled_equals_single_rank": ok2, "gather_in_timed_region": True, "exchange": "rgb8" if args.rgb8 else "f32"}}
+        except Exception as e:   # the headline line must not be lost to a failure in the extra runs
+            extra = {"error": f"{type(e).__name__}: {e}"}
+
+    configs_file = None
+    if args.all_configs and world == 1 and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs
+        configs_file = bench_configs.run_all(os.path.join(ROOT, "profiles", "r02_configs.json"))
 
     if rank == 0:
-        if args.save:
-            rt.write_bmp(args.save, frames[(args.steps - 1) % D].cpu().numpy())
         value = rays / elapsed / 1e6
+        if roofline and roofline.get("_step_valu") is not None:
+            sv, stf = roofline.pop("_step_valu"), roofline.pop("_step_traffic")
+            ms_step = elapsed / args.steps * 1e3
+            roofline["step_check"] = {"note": "all kernels of a frame over the pipelined frame time (N = 1 only: the counters are one GPU's)",
+                                      "valu_insts_per_step": int(sv), "valu_frac": round(sv / (ms_step * 1e-3) / 1e9 / VALU_PEAK_GIPS, 4) if world == 1 else None,
+                                      "hbm_bytes_per_step": int(stf), "hbm_frac": round(stf / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None}
         out = {
             "metric": "Mrays/sec (primary+secondary) at 1080p", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "frames_in_flight": D, "single_frame_latency_ms": round(latency_ms, 4), "assembled_equals_single_rank": assembled_ok,
-            "config": {"workload": f"C2: {flat.info.n_tris}-triangle textured height field + 2 bump spheres, ambient+directional+point light, "
-                                   f"{W}x{H}, {ax}x{ay} samples/pixel, tiles sharded over {world} GPU(s)",
-                       "width": W, "height": H, "samples_per_pixel": ax * ay, "rays_per_step": rays // args.steps,
-                       "eye": list(eye), "rot_x": rot_x, "max_depth": rt.MAX_REFLECTIONS},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "exchange": None if world == 1 else ("rgb8" if args.rgb8 else "f32"),
+            "config": {"workload": wl.label, "width": wl.W, "height": wl.H, "samples_per_pixel": wl.aa[0] * wl.aa[1], "rays_per_step": rays // args.steps,
+                       "eye": list(wl.eye), "rot_x": wl.rot_x, "max_depth": wl.max_depth},
+            "roofline": roofline, "cpu_baseline": cpu, "baseline_configs": extra,
         }
+        if configs_file:
+            out["all_configs"] = os.path.relpath(configs_file, ROOT)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -50,6 +50,8 @@ typedef struct rt_stats {
 	float    nearest_ms;       /* hipEvent time spent in the nearest-hit traversal kernel (dominant kernel) */
 	float    shadow_ms;        /* hipEvent time spent in the shadow traversal kernel */
 	float    max_walk;         /* longest nearest-hit walk of the call in nodes (only when RT_FLAG_COUNTERS) */
+	uint64_t steps_nearest;    /* node steps of the PACKET walks (one per wave and node visited, x 64 rays): nodes / (64 * steps) is the */
+	uint64_t steps_shadow;     /* fraction of a packet's lanes whose own ray is in the node (only when RT_FLAG_COUNTERS)              */
 } rt_stats;
 
 #define RT_FLAG_COUNTERS   1u   /* count nodes / primitive tests in the traversal kernels (slower) */
@@ -190,6 +192,16 @@ int rt_tiles_merge(rt_scene* scene, const float* src_dev, float* dst_dev, int wi
 int64_t rt_tiles_count(int width, int height, int tile_rank, int tile_ranks);
 int rt_tiles_pack(rt_scene* scene, const float* frame_dev, float* packed_dev, int width, int height, int tile_rank, int tile_ranks, void* stream);
 int rt_tiles_unpack(rt_scene* scene, const float* packed_dev, float* frame_dev, int width, int height, int tile_rank, int tile_ranks, void* stream);
+
+/* The same exchange with 8-bit pixels: 3 B instead of 12 B per pixel cross xGMI.  Quantised on the device
+ * exactly as rt_quantize_rgb8 does on the host (EasyBMP's byte order is applied by the BMP writer, not here).
+ *   rt_tiles_pack_rgb8      float frame (row 0 = bottom) -> rt_tiles_count()*256*3 BYTES, the owned tiles in tile order
+ *   rt_tiles_unpack_rgb8    such a payload -> the 8-bit frame frame8_dev (width*height*3 bytes, row 0 = TOP as rt_quantize_rgb8 writes)
+ *   rt_tiles_quantize_rgb8  float frame -> 8-bit frame for the owned tiles only (the root's own share; (0, 1) = the whole frame)
+ * Enqueued on `stream`, not waited for, like rt_tiles_pack. */
+int rt_tiles_pack_rgb8(rt_scene* scene, const float* frame_dev, uint8_t* packed_dev, int width, int height, int tile_rank, int tile_ranks, void* stream);
+int rt_tiles_unpack_rgb8(rt_scene* scene, const uint8_t* packed_dev, uint8_t* frame8_dev, int width, int height, int tile_rank, int tile_ranks, void* stream);
+int rt_tiles_quantize_rgb8(rt_scene* scene, const float* frame_dev, uint8_t* frame8_dev, int width, int height, int tile_rank, int tile_ranks, void* stream);
 
 const char* rt_last_error(void);
 const char* rt_version(void);

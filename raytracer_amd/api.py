@@ -194,6 +194,18 @@ class Scene:
         check(capi.load().rt_tiles_unpack(self._h, C.c_void_p(packed_ptr), C.c_void_p(frame_ptr), width, height, tile_rank, tile_ranks, C.c_void_p(stream or 0)))
 
 
+def _tiles_rgb8(name):
+    def call(self, src_ptr, dst_ptr, width, height, tile_rank, tile_ranks, stream=None):
+        check(getattr(capi.load(), name)(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), width, height, tile_rank, tile_ranks, C.c_void_p(stream or 0)))
+    call.__doc__ = name + " (include/rt_capi.h): the tile exchange with 8-bit pixels, quantised on the device"
+    return call
+
+
+Scene.tiles_pack_rgb8 = _tiles_rgb8("rt_tiles_pack_rgb8")
+Scene.tiles_unpack_rgb8 = _tiles_rgb8("rt_tiles_unpack_rgb8")
+Scene.tiles_quantize_rgb8 = _tiles_rgb8("rt_tiles_quantize_rgb8")
+
+
 def quantize_rgb8(rgb):
     """[H, W, 3] float, row 0 = bottom  ->  [H, W, 3] uint8, row 0 = top (clamp, *255 + 0.5, NaN -> 0)."""
     rgb = f32(rgb)

@@ -21,7 +21,7 @@ SYMBOLS = [
     "rt_load_scene_json", "rt_load_scene_json_text", "rt_flat_scene_save", "rt_flat_scene_load", "rt_flat_scene_free",
     "rt_camera_setup", "rt_write_bmp", "rt_quantize_rgb8", "rt_device_count", "rt_scene_upload", "rt_scene_free",
     "rt_render", "rt_render_submit", "rt_render_wait", "rt_render_host", "rt_trace_batch", "rt_trace_pick", "rt_pick_narration", "rt_intersect_batch", "rt_intersect_batch_static", "rt_shadow_batch", "rt_tiles_merge",
-    "rt_tiles_count", "rt_tiles_pack", "rt_tiles_unpack", "rt_last_error", "rt_version",
+    "rt_tiles_count", "rt_tiles_pack", "rt_tiles_unpack", "rt_tiles_pack_rgb8", "rt_tiles_unpack_rgb8", "rt_tiles_quantize_rgb8", "rt_last_error", "rt_version",
 ]
 
 
@@ -43,7 +43,7 @@ class rt_stats(C.Structure):
     _fields_ = [("rays_nearest", C.c_uint64), ("rays_shadow", C.c_uint64), ("nodes_nearest", C.c_uint64), ("prims_nearest", C.c_uint64),
                 ("nodes_shadow", C.c_uint64), ("prims_shadow", C.c_uint64),
                 ("levels", C.c_uint64), ("batch_splits", C.c_uint64), ("gpu_ms", C.c_float), ("nearest_ms", C.c_float),
-                ("shadow_ms", C.c_float), ("max_walk", C.c_float)]
+                ("shadow_ms", C.c_float), ("max_walk", C.c_float), ("steps_nearest", C.c_uint64), ("steps_shadow", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}
@@ -105,7 +105,7 @@ def load():
     lib.rt_intersect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]
     lib.rt_intersect_batch_static.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rt_shadow_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]
-    for name in ("rt_tiles_pack", "rt_tiles_unpack", "rt_tiles_merge"):
+    for name in ("rt_tiles_pack", "rt_tiles_unpack", "rt_tiles_merge", "rt_tiles_pack_rgb8", "rt_tiles_unpack_rgb8", "rt_tiles_quantize_rgb8"):
         getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.rt_tiles_count.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.rt_write_bmp.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]

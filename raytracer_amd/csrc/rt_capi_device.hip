@@ -673,6 +673,7 @@ int finish(rt_scene* sc, rt_scene::Lane* ln, hipStream_t st, Run& run, rt_stats*
 	if (run.flags & RT_FLAG_COUNTERS) {
 		run.stats.nodes_nearest = ln->ctrHost->nodes_nearest; run.stats.prims_nearest = ln->ctrHost->prims_nearest;
 		run.stats.nodes_shadow = ln->ctrHost->nodes_shadow; run.stats.prims_shadow = ln->ctrHost->prims_shadow;
+		run.stats.steps_nearest = ln->ctrHost->steps_nearest; run.stats.steps_shadow = ln->ctrHost->steps_shadow;
 		run.stats.max_walk = (float)ln->ctrHost->pad;   // longest nearest-hit walk of the call, in nodes (diagnostic)
 	}
 #if RT_PROF
@@ -1030,7 +1031,7 @@ int rt_render_wait(rt_scene* sc, uint64_t ticket, rt_stats* stats) {
 		const rt_stats& p = job->part[k];
 		total.rays_nearest += p.rays_nearest; total.rays_shadow += p.rays_shadow; total.batch_splits += p.batch_splits;
 		total.nodes_nearest += p.nodes_nearest; total.prims_nearest += p.prims_nearest; total.nodes_shadow += p.nodes_shadow; total.prims_shadow += p.prims_shadow;
-		total.nearest_ms += p.nearest_ms; total.shadow_ms += p.shadow_ms;
+		total.nearest_ms += p.nearest_ms; total.shadow_ms += p.shadow_ms; total.steps_nearest += p.steps_nearest; total.steps_shadow += p.steps_shadow;
 		total.levels = std::max(total.levels, p.levels); total.max_walk = std::max(total.max_walk, p.max_walk);
 	}
 	retire();
@@ -1228,6 +1229,23 @@ int rt_tiles_unpack(rt_scene* sc, const float* packed_dev, float* frame_dev, int
 }
 int rt_tiles_merge(rt_scene* sc, const float* src_dev, float* dst_dev, int width, int height, int tile_rank, int tile_ranks, void* stream) {
 	return tilesCopy(sc, src_dev, dst_dev, width, height, tile_rank, tile_ranks, stream, 2);
+}
+
+static int tilesRgb8(rt_scene* sc, const void* src, uint8_t* dst, int width, int height, int tile_rank, int tile_ranks, void* stream, int mode) {
+	if (!sc || !src || !dst || rt_tiles_count(width, height, tile_rank, tile_ranks) < 0) { rt::set_error("rt_tiles_*_rgb8: bad argument"); return RT_EINVAL; }
+	HIPCHK(hipSetDevice(sc->device));
+	rtk_tiles_rgb8(static_cast<hipStream_t>(stream), src, dst, width, height, tile_rank, tile_ranks, (uint32_t)(localTiles(width, height, tile_rank, tile_ranks) * 256), mode);
+	if (int rcL = launchesOk()) return rcL;
+	return RT_OK;
+}
+int rt_tiles_pack_rgb8(rt_scene* sc, const float* frame_dev, uint8_t* packed_dev, int width, int height, int tile_rank, int tile_ranks, void* stream) {
+	return tilesRgb8(sc, frame_dev, packed_dev, width, height, tile_rank, tile_ranks, stream, 0);
+}
+int rt_tiles_unpack_rgb8(rt_scene* sc, const uint8_t* packed_dev, uint8_t* frame8_dev, int width, int height, int tile_rank, int tile_ranks, void* stream) {
+	return tilesRgb8(sc, packed_dev, frame8_dev, width, height, tile_rank, tile_ranks, stream, 1);
+}
+int rt_tiles_quantize_rgb8(rt_scene* sc, const float* frame_dev, uint8_t* frame8_dev, int width, int height, int tile_rank, int tile_ranks, void* stream) {
+	return tilesRgb8(sc, frame_dev, frame8_dev, width, height, tile_rank, tile_ranks, stream, 2);
 }
 
 }  // extern "C"

@@ -88,6 +88,7 @@ struct RtCounters {
 	uint32_t pad2;
 	unsigned long long nodes_nearest, prims_nearest;   // RT_FLAG_COUNTERS: 64 B nodes read / primitive tests in k_intersect
 	unsigned long long nodes_shadow, prims_shadow;     // ... and in the shadow kernels
+	unsigned long long steps_nearest, steps_shadow;    // RT_FLAG_COUNTERS: node steps of the packet walks (one per wave and node, whatever the number of rays in it)
 #if RT_PROF
 	unsigned long long trace[2][4][RT_TRACE_LEN];      // RT_PROF builds: step traces of four waves of the two packet kernels
 	unsigned long long laneHist[2][8];                 // node steps by number of rays in the node: 1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64
@@ -131,3 +132,4 @@ void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, bool count, Rt
 void rtk_shadow_query(hipStream_t st, const DevScene& S, bool csg, const float* point, const float* lightPos, uint32_t n, uint8_t* lit, float* shadow);
 void rtk_resolve(hipStream_t st, RtAccum A, int W, int H, int tileRank, int tileRanks, uint32_t lp0, uint32_t count, uint32_t aaSq, int linear, float* rgb);
 void rtk_tiles_copy(hipStream_t st, const float* src, float* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode);
+void rtk_tiles_rgb8(hipStream_t st, const void* src, uint8_t* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode);

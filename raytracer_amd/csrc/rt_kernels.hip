@@ -234,6 +234,7 @@ struct Trav {
 	float tmin; uint32_t best, bestKey, bestTag;   // nearest
 	f3 shadow; float len; bool lit;                 // any-hit
 	unsigned long long cntNodes, cntPrims;
+	uint32_t cntSteps;   // packet walks, COUNT builds: node steps of the wave (the same in every lane)
 #if RT_PROF
 	uint32_t steps;
 #endif
@@ -245,7 +246,7 @@ __device__ __forceinline__ void travInit(const DevScene& S, Trav& T, f3 e, f3 d)
 	T.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 	T.special = !(fabsf(T.inv.x) <= 3.0e38f && fabsf(T.inv.y) <= 3.0e38f && fabsf(T.inv.z) <= 3.0e38f);
 	T.sp = 0; T.cur = kEmpty;
-	T.cntNodes = 0; T.cntPrims = 0;
+	T.cntNodes = 0; T.cntPrims = 0; T.cntSteps = 0;
 #if RT_PROF
 	T.steps = 0;
 #endif
@@ -585,6 +586,7 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			h0 = h0 && inSub && !T.special; h1 = h1 && inSub && !T.special;
 			a0 = (a0 || T.special) && inSub; a1 = (a1 || T.special) && inSub;
 			if (COUNT || RT_PROF) T.cntNodes += inSub ? 1u : 0u;
+			if (COUNT) T.cntSteps++;
 			if (cons) { h0 = h0 || a0; h1 = h1 || a1; }   // too close to call = visit
 			else if (__ballot(a0 || a1) != 0) {   // too close to call somewhere in the wave (rare): the reference's own arithmetic decides
 				if (a0) { const float t = boxIntersect(b0, T.e, T.d, false); h0 = !(t < 0 || t > tlimit); }
@@ -702,7 +704,7 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 			a0A = (a0A || A.special) && inA; a1A = (a1A || A.special) && inA;
 			h0B = h0B && inB && !B.special; h1B = h1B && inB && !B.special;
 			a0B = (a0B || B.special) && inB; a1B = (a1B || B.special) && inB;
-			if (COUNT) { A.cntNodes += inA ? 1u : 0u; B.cntNodes += inB ? 1u : 0u; }
+			if (COUNT) { A.cntNodes += inA ? 1u : 0u; B.cntNodes += inB ? 1u : 0u; A.cntSteps++; }
 			if (cons) { h0A = h0A || a0A; h1A = h1A || a1A; h0B = h0B || a0B; h1B = h1B || a1B; }
 			else if (__ballot(a0A || a1A || a0B || a1B) != 0) {   // too close to call somewhere (rare): the reference's own arithmetic decides
 				if (a0A) { const float tt = boxIntersect(b0, A.e, A.d, false); h0A = !(tt < 0 || tt > 1.0f); }
@@ -870,7 +872,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RtQueue rq, ui
 	uint32_t idx = kInactive;
 	WorkPool pool = firstPool(n);
 	Trav T;
-	T.cur = kEmpty; T.sp = 0; T.cntNodes = 0; T.cntPrims = 0;
+	T.cur = kEmpty; T.sp = 0; T.cntNodes = 0; T.cntPrims = 0; T.cntSteps = 0;
 	unsigned long long cn = 0, cp = 0;
 	for (;;) {
 		const uint32_t got = fetchWork(idx == kInactive, pool, &ctr->head_nearest, n);
@@ -943,7 +945,7 @@ __global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_intersect_
 		const uint32_t g = (uint32_t)(((unsigned long long)(k / kPacketGroup) * groupStride) % nGroups);
 		return g * kPacketGroup + k % kPacketGroup;
 	};
-	unsigned long long cn = 0, cp = 0;
+	unsigned long long cn = 0, cp = 0, cs = 0;
 	TR_DECL(0)
 	struct Rays { f3 e, d; bool alive; };
 	auto loadRays = [&](uint32_t pk) {
@@ -966,7 +968,7 @@ __global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_intersect_
 		const Rays cur = loadRays(pk);
 		const uint32_t idx = pk * 64u + lane;
 		Trav T;
-		T.cur = kEmpty; T.best = RT_NO_HIT; T.tmin = 0; T.bestTag = 0; T.cntNodes = 0; T.cntPrims = 0;
+		T.cur = kEmpty; T.best = RT_NO_HIT; T.tmin = 0; T.bestTag = 0; T.cntNodes = 0; T.cntPrims = 0; T.cntSteps = 0;
 		if (cur.alive) travInit<false>(S, T, cur.e, cur.d);
 		TR(2, __popcll(__ballot(T.cur != kEmpty)));
 		packetTraverse<false, CSG, COUNT>(S, ws, T, cur.alive TR_ARG);
@@ -978,12 +980,12 @@ __global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_intersect_
 			qsf(hq, HQ_T, idx, (cur.alive && T.best != RT_NO_HIT) ? T.tmin : 0.0f);
 			if (CSG) qsu(hq, HQ_TAG, idx, T.bestTag);
 		}
-		if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
+		if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; cs += T.cntSteps; }
 		TR(11, 0);
 		WL_PACKET(T, cur.alive);
 	}
 	WL_END();
-	if (COUNT) { atomicAdd(&ctr->nodes_nearest, cn); atomicAdd(&ctr->prims_nearest, cp); }
+	if (COUNT) { atomicAdd(&ctr->nodes_nearest, cn); atomicAdd(&ctr->prims_nearest, cp); if (lane == 0) atomicAdd(&ctr->steps_nearest, cs); }
 }
 
 // hit queue -> caller-visible (hit, id, t)
@@ -1328,7 +1330,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq,
 	uint32_t idx = kInactive;
 	WorkPool pool = firstPool(total);
 	Trav T;
-	T.cur = kEmpty; T.sp = 0; T.cntNodes = 0; T.cntPrims = 0; T.lit = true; T.shadow = mk3(1.0f, 1.0f, 1.0f);
+	T.cur = kEmpty; T.sp = 0; T.cntNodes = 0; T.cntPrims = 0; T.cntSteps = 0; T.lit = true; T.shadow = mk3(1.0f, 1.0f, 1.0f);
 	unsigned long long cn = 0, cp = 0;
 	for (;;) {
 		const uint32_t got = fetchWork(idx == kInactive, pool, &ctr->head_shadow, total);
@@ -1378,7 +1380,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW_WAVES_PER_SIMD) void k_shadow_poi
 	const PacketLds ws = packetLdsInit(S);
 	const uint32_t packetsPerLight = (nsurf + 63u) / 64u;
 	const uint32_t totalPackets = packetsPerLight * nLights;
-	unsigned long long cn = 0, cp = 0;
+	unsigned long long cn = 0, cp = 0, cs = 0;
 	TR_DECL(1)
 	// light-minor numbering: the packets of one group of 64 surfaces towards every light are neighbours
 	auto surfaceOf = [&](uint32_t q) { return (q / nLights) * 64u + lane; };
@@ -1399,7 +1401,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW_WAVES_PER_SIMD) void k_shadow_poi
 		const uint32_t s = surfaceOf(q);
 		const bool alive = s < nsurf;
 		Trav T;
-		T.cur = kEmpty; T.lit = true; T.shadow = mk3(1.0f, 1.0f, 1.0f); T.cntNodes = 0; T.cntPrims = 0;
+		T.cur = kEmpty; T.lit = true; T.shadow = mk3(1.0f, 1.0f, 1.0f); T.cntNodes = 0; T.cntPrims = 0; T.cntSteps = 0;
 		if (alive) {
 			f3 Ld, lightPos;
 			pointLightGeometry(S.lights[lightIndex], p, Ld, lightPos);
@@ -1410,7 +1412,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW_WAVES_PER_SIMD) void k_shadow_poi
 		TR(9, 0);
 		q = fetchPacket(feed, head, totalPackets);
 		TR(10, 0);
-		if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; }
+		if (COUNT) { cn += T.cntNodes; cp += T.cntPrims; cs += T.cntSteps; }
 		if (alive && T.lit) {
 			const rt_light L = S.lights[lightIndex];
 			const Surface sf = loadSurface(sq, s);
@@ -1425,7 +1427,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW_WAVES_PER_SIMD) void k_shadow_poi
 		WL_PACKET(T, alive);
 	}
 	WL_END();
-	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
+	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); if (lane == 0) atomicAdd(&ctr->steps_shadow, cs); }
 }
 
 // Two lights per packet (packetTraverse2): lights lightList[2j] and lightList[2j + 1] for the same 64 surfaces; the surface
@@ -1437,7 +1439,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW2_WAVES_PER_SIMD) void k_shadow_po
 	const uint32_t lane = __lane_id();
 	const PacketLds ws = packetLdsInit(S);
 	const uint32_t totalPackets = ((nsurf + 63u) / 64u) * nPairs;
-	unsigned long long cn = 0, cp = 0;
+	unsigned long long cn = 0, cp = 0, cs = 0;
 	PacketFeed feed = firstPackets(totalPackets);
 	uint32_t q = feed.next < feed.end ? feed.next++ : kInactive;
 	while (q != kInactive) {
@@ -1447,8 +1449,8 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW2_WAVES_PER_SIMD) void k_shadow_po
 		f3 p = mk3(0, 0, 0);
 		if (alive) p = mk3(qf(sq, SQ_PX, s), qf(sq, SQ_PY, s), qf(sq, SQ_PZ, s));
 		Trav TA, TB;
-		TA.cur = kEmpty; TA.lit = true; TA.shadow = mk3(1.0f, 1.0f, 1.0f); TA.cntNodes = 0; TA.cntPrims = 0;
-		TB.cur = kEmpty; TB.lit = true; TB.shadow = mk3(1.0f, 1.0f, 1.0f); TB.cntNodes = 0; TB.cntPrims = 0;
+		TA.cur = kEmpty; TA.lit = true; TA.shadow = mk3(1.0f, 1.0f, 1.0f); TA.cntNodes = 0; TA.cntPrims = 0; TA.cntSteps = 0;
+		TB.cur = kEmpty; TB.lit = true; TB.shadow = mk3(1.0f, 1.0f, 1.0f); TB.cntNodes = 0; TB.cntPrims = 0; TB.cntSteps = 0;
 		if (alive) {
 			f3 Ld, lightPos;
 			pointLightGeometry(S.lights[lightA], p, Ld, lightPos);
@@ -1458,7 +1460,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW2_WAVES_PER_SIMD) void k_shadow_po
 		}
 		packetTraverse2<CSG, COUNT>(S, ws, TA, TB, alive, alive);
 		q = fetchPacket(feed, &ctr->head_shadow, totalPackets);
-		if (COUNT) { cn += TA.cntNodes + TB.cntNodes; cp += TA.cntPrims + TB.cntPrims; }
+		if (COUNT) { cn += TA.cntNodes + TB.cntNodes; cp += TA.cntPrims + TB.cntPrims; cs += 2u * TA.cntSteps; }   // a step of the two-ray walk serves two rays per lane
 		if (alive && (TA.lit || TB.lit)) {
 			const Surface sf = loadSurface(sq, s);
 			f3 cA = mk3(0, 0, 0), cB = cA;
@@ -1484,7 +1486,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW2_WAVES_PER_SIMD) void k_shadow_po
 			accumAdd2(A, sf.pixKey / aaSq, cA, hasA, cB, hasB);
 		}
 	}
-	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); }
+	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); if (lane == 0) atomicAdd(&ctr->steps_shadow, cs); }
 }
 
 // Rectangular / circular area light `lightIndex`: one lane per (surface, sample), samples of one surface in
@@ -1501,7 +1503,7 @@ __global__ __launch_bounds__(kBlock, RT_AREA_WAVES_PER_SIMD) void k_shadow_area(
 	uint32_t s = kInactive;
 	f3 c = mk3(0, 0, 0), p = c;
 	Trav T;
-	T.cur = kEmpty; T.lit = true; T.shadow = mk3(1.0f, 1.0f, 1.0f); T.cntNodes = 0; T.cntPrims = 0;
+	T.cur = kEmpty; T.lit = true; T.shadow = mk3(1.0f, 1.0f, 1.0f); T.cntNodes = 0; T.cntPrims = 0; T.cntSteps = 0;
 	f3 lightPos = c;
 	if (live) {
 		s = (uint32_t)(j / ns);
@@ -1527,7 +1529,7 @@ __global__ __launch_bounds__(kBlock, RT_AREA_WAVES_PER_SIMD) void k_shadow_area(
 	f3 w = mk3(0, 0, 0);
 	uint32_t pixKey = 0;
 	if (live) {
-		if (COUNT) { atomicAdd(&ctr->nodes_shadow, T.cntNodes); atomicAdd(&ctr->prims_shadow, T.cntPrims); }
+		if (COUNT) { atomicAdd(&ctr->nodes_shadow, T.cntNodes); atomicAdd(&ctr->prims_shadow, T.cntPrims); if ((threadIdx.x & 63) == 0) atomicAdd(&ctr->steps_shadow, (unsigned long long)T.cntSteps); }
 		if (T.lit) {
 			const Surface sf = loadSurface(sq, s);
 			c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
@@ -1696,6 +1698,32 @@ __global__ __launch_bounds__(kBlock) void k_tiles_copy(const float* src, float* 
 	}
 }
 
+// The same exchange with 8-bit pixels (3 B instead of 12 B per pixel over xGMI).  Quantised exactly as
+// rt_quantize_rgb8 does on the host: NaN and negatives -> 0, above 1 -> 255, else c * 255 + 0.5 truncated.
+//   mode 0  pack:   float frame (row 0 = bottom) -> dense bytes, 256 x 3 per owned tile, in tile order
+//   mode 1  unpack: dense bytes -> 8-bit frame, row 0 = TOP (the BMP's order, as rt_quantize_rgb8 writes it)
+//   mode 2  direct: float frame -> 8-bit frame, owned tiles only (the root's own share)
+__device__ __forceinline__ uint8_t quantize8(float c) {
+	if (!(c > 0.0f)) c = 0.0f;
+	if (c > 1.0f) c = 1.0f;
+	return (uint8_t)(c * 255.0f + 0.5f);
+}
+__global__ __launch_bounds__(kBlock) void k_tiles_rgb8(const void* src, uint8_t* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= count) return;
+	int x, y;
+	const bool inside = tilePixel(i, W, H, tileRank, tileRanks, x, y);
+	if (mode == 0) {   // padding slots of partial edge tiles are written too (zero): the payload has no undefined bytes
+		const float* f = static_cast<const float*>(src);
+		for (int k = 0; k < 3; k++) dst[3 * (size_t)i + k] = inside ? quantize8(f[3 * ((size_t)y * W + x) + k]) : (uint8_t)0;
+		return;
+	}
+	if (!inside) return;
+	const size_t out = (size_t)(H - 1 - y) * W + x;
+	if (mode == 1) { const uint8_t* b = static_cast<const uint8_t*>(src); for (int k = 0; k < 3; k++) dst[3 * out + k] = b[3 * (size_t)i + k]; }
+	else { const float* f = static_cast<const float*>(src); for (int k = 0; k < 3; k++) dst[3 * out + k] = quantize8(f[3 * ((size_t)y * W + x) + k]); }
+}
+
 inline unsigned gridFor(unsigned long long n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 // persistent kernels: enough workgroups to fill every CU once (the kernels loop over the work themselves)
 inline unsigned gridPersistent(unsigned long long n, int maxBlocks) { return (unsigned)std::min<unsigned long long>((n + kBlock - 1) / kBlock, (unsigned long long)maxBlocks); }
@@ -1859,4 +1887,7 @@ void rtk_resolve(hipStream_t st, RtAccum A, int W, int H, int tileRank, int tile
 }
 void rtk_tiles_copy(hipStream_t st, const float* src, float* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode) {
 	RT_LAUNCH(k_tiles_copy, count, st, src, dst, W, H, tileRank, tileRanks, count, mode);
+}
+void rtk_tiles_rgb8(hipStream_t st, const void* src, uint8_t* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode) {
+	RT_LAUNCH(k_tiles_rgb8, count, st, src, dst, W, H, tileRank, tileRanks, count, mode);
 }

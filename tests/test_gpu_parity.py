@@ -190,6 +190,35 @@ def test_render_is_deterministic_and_tiles_compose(gpu_scenes, flat_scenes):
     assert np.array_equal(bits(full.cpu().numpy()), bits(a))
 
 
+def test_tiles_exchange_with_8_bit_pixels_equals_host_quantiser(gpu_scenes, flat_scenes):
+    """The exchange with 8-bit pixels (rt_tiles_pack_rgb8 / _unpack_rgb8 / _quantize_rgb8): the frame assembled from three ranks'
+    byte payloads is, byte for byte, rt_quantize_rgb8 of the single-rank float frame -- NaN, negative and > 1 pixels included."""
+    import torch
+    import raytracer_amd as rt
+    fs = flat_scenes("c")
+    W, H, ranks = 200, 100, 3          # partial edge tiles, ragged tile counts
+    cam = rt.Camera(fs.fov, W, H)
+    sc = gpu_scenes("c")
+    whole = torch.from_numpy(sc.render(W, H, camera=cam)).cuda()
+    whole[3, 5] = torch.tensor([float("nan"), -0.25, 7.0], device="cuda")      # the quantiser's corner cases
+    whole[H - 1, W - 1] = torch.tensor([1.0, 0.0, 0.5], device="cuda")
+    want = rt.quantize_rgb8(whole.cpu().numpy())
+    frame8 = torch.full((H, W, 3), 99, dtype=torch.uint8, device="cuda")
+    sc.tiles_quantize_rgb8(whole.data_ptr(), frame8.data_ptr(), W, H, 0, ranks)      # the root's own share
+    for rank in range(1, ranks):
+        n = sc.tiles_count(W, H, rank, ranks)
+        packed = torch.full((n * 256 * 3,), 77, dtype=torch.uint8, device="cuda")
+        sc.tiles_pack_rgb8(whole.data_ptr(), packed.data_ptr(), W, H, rank, ranks)
+        sc.tiles_unpack_rgb8(packed.data_ptr(), frame8.data_ptr(), W, H, rank, ranks)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame8.cpu().numpy(), want)
+    # (0, 1) quantises the whole frame in one call
+    all8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    sc.tiles_quantize_rgb8(whole.data_ptr(), all8.data_ptr(), W, H, 0, 1)
+    torch.cuda.synchronize()
+    assert np.array_equal(all8.cpu().numpy(), want)
+
+
 def test_tiles_pack_gather_unpack_on_device(gpu_scenes, flat_scenes):
     """The multi-GPU assembly (bench.py, raytracer_amd.distributed) on one device: every rank's tiles packed, unpacked into
     the root's frame -- stream-ordered calls, no host synchronisation in between -- give the single-rank frame."""

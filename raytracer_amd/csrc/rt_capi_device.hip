@@ -23,6 +23,7 @@
 namespace {
 
 #define RT_MAX_LANES 8
+#define RT_MAX_LEVELS 32   /* max_depth <= 30 is checked by the entry points: levels 0 .. 30 */
 #define RT_MAX_INFLIGHT 4
 #define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rt::set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); return RT_EHIP; } } while (0)
 
@@ -82,6 +83,7 @@ struct rt_scene {
 	DevScene dev{};
 	bool hasCsg = false;
 	bool hasTransmissive = false;   // some material transmits: k_shade queues requests for k_transmit
+	bool hasReflective = false;     // some material reflects (with hasTransmissive: how many children a hit can have)
 	// some textured triangle reflects: its hits leave records for k_texel_fix (RtTexFix in rt_kernels.h).  The per-pixel list heads
 	// are shared by the lanes like the accumulators (shards own disjoint pixels), the records are per lane.
 	bool texelFix = false;
@@ -101,6 +103,13 @@ struct rt_scene {
 		RtQueue ray[2]{}, hitq{}, surfq{}, transq{};
 		RtCounters* ctr = nullptr;       // device
 		RtCounters* ctrHost = nullptr;   // pinned
+		// One counter block per level of the ray tree, for the level loop that runs ahead of the host (Run::levelsAhead): the
+		// kernels of level L append into block L and read level L - 1's count from block L - 1, so no block is reset or reused
+		// while kernels queued behind it still need it; the host reads block L back (pinned mirror, event) when it gets there.
+		RtCounters* lvl = nullptr;       // device, RT_MAX_LEVELS blocks
+		RtLevelReport* report = nullptr;      // pinned, mapped: one slot per level, written by k_publish
+		RtLevelReport* reportDev = nullptr;   // the same memory as the device addresses it
+		uint32_t reportSeq = 0;               // last sequence number handed out (a slot is fresh when it shows the number it was queued with)
 		hipEvent_t ev[6]{};              // 0,1 whole call; 2,3 nearest kernel; 4,5 shadow kernels
 		hipStream_t stream = nullptr;    // owned, non-blocking (lane 0 also runs on the caller's stream)
 		RtTexRec* texRec = nullptr;      // texelFix only
@@ -174,6 +183,12 @@ struct rt_scene {
 		allocs.push_back(p);
 		ln.ctr = static_cast<RtCounters*>(p);
 		HIPCHK(hipHostMalloc((void**)&ln.ctrHost, sizeof(RtCounters), hipHostMallocDefault));
+		HIPCHK(hipMalloc(&p, sizeof(RtCounters) * RT_MAX_LEVELS));
+		allocs.push_back(p);
+		ln.lvl = static_cast<RtCounters*>(p);
+		HIPCHK(hipHostMalloc((void**)&ln.report, sizeof(RtLevelReport) * RT_MAX_LEVELS, hipHostMallocMapped));
+		memset(ln.report, 0, sizeof(RtLevelReport) * RT_MAX_LEVELS);
+		HIPCHK(hipHostGetDevicePointer((void**)&ln.reportDev, ln.report, 0));
 		for (auto& e : ln.ev) HIPCHK(hipEventCreate(&e));
 		if (ownStream) HIPCHK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
 		return RT_OK;
@@ -630,10 +645,98 @@ struct Run {
 		return RT_OK;
 	}
 
+	// The same level loop running AHEAD of the host.  Above, every level costs a host round trip (the counts decide the next
+	// launches), 35 - 80 us during which the lane's stream is empty: half the frame time of the bundled scenes, whose ray trees
+	// are 17 levels of a few hundred thousand rays.  Here the kernels of level L read their item counts on the device (from
+	// level L - 1's counter block) and are launched with bounds for their grids, so the host only has to know how far the ray
+	// tree goes: it queues `ahead` levels beyond the last one whose counts it has read back, and stops when a level it reads
+	// turns out empty (the levels already queued behind that one find zero items and leave at once).  Bounds: a hit has at
+	// most one reflected and one transmitted child, so level L holds at most (children per hit)^k times the rays of level
+	// L - k, and never more than the queue does.  Not for counting / per-kernel timing runs, narration, or scenes that keep
+	// texel records (those read more than the counts after each level): they use levels().
+	// Waits until k_publish has written the report queued with sequence number `seq`.  Spins for a while (the levels this loop is
+	// for take tens of microseconds), then sleeps between looks; a GPU error or ten seconds without the report end the wait.
+	int awaitReport(const RtLevelReport* slot, uint32_t seq, RtLevelReport& out) {
+		const auto t0 = std::chrono::steady_clock::now();
+		for (uint64_t spins = 0;; spins++) {
+			if (__atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) == seq) {
+				out.next_count = slot->next_count; out.surf_count = slot->surf_count; out.overflow = slot->overflow; out.seq = seq;
+				return RT_OK;
+			}
+			if (spins < 4000) { __builtin_ia32_pause(); continue; }
+			if ((spins & 63) == 0) {
+				const hipError_t e = hipStreamQuery(st);
+				if (e != hipSuccess && e != hipErrorNotReady) { rt::set_error(std::string("waiting for a level's counts: ") + hipGetErrorString(e)); return RT_EHIP; }
+				if (e == hipSuccess && __atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) != seq &&
+				    std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) { rt::set_error("a level's counts never arrived"); return RT_EHIP; }
+			}
+			std::this_thread::sleep_for(std::chrono::microseconds(spins < 8000 ? 5 : 50));
+		}
+	}
+	bool canRunAhead() const {
+		static const bool off = getenv("RT_NO_LEVELS_AHEAD") != nullptr;
+		return !off && !(flags & (RT_FLAG_COUNTERS | RT_FLAG_TIME_KERNELS)) && !pick.ev && !sc->texelFix;
+	}
+	int levelsAhead(uint32_t r0, uint32_t cnt) {
+		static const int ahead = (int)std::max<uint32_t>(1, std::min<uint32_t>(8, envU32("RT_LEVELS_AHEAD", 2)));
+		const uint32_t fan = (sc->hasReflective ? 1u : 0u) + (sc->hasTransmissive ? 1u : 0u);
+		const int lastLevel = fan == 0 ? 0 : std::min(maxDepth, RT_MAX_LEVELS - 1);
+		RtCounters* const L = ln->lvl;
+		HIPCHK(hipMemsetAsync(L, 0, sizeof(RtCounters) * (size_t)(lastLevel + 1), st));
+		if (src.camera) rtk_generate(st, src.cam, src.W, src.H, src.aaX, src.aaY, src.tileRank, src.tileRanks, r0, cnt, ln->ray[0]);
+		else rtk_load_rays(st, src.a + 3 * (size_t)r0, src.b + 3 * (size_t)r0, cnt, 1, ln->ray[0], r0);
+		const bool shadows = sc->shadowRaysPerSurface > 0;
+		int queued = 0, read = 0;          // levels queued so far / levels whose counts the host has read
+		uint64_t known = cnt;              // rays of level `read` (exact)
+		uint64_t nearRays = 0, shadowRays = 0, nLevels = 0;
+		uint32_t seqOf[RT_MAX_LEVELS] = {};
+		bool overflow = false;
+		int cur = 0;
+		for (;;) {
+			// queue levels while they are within `ahead` of what the host knows and can still hold rays
+			while (queued <= lastLevel && queued < read + ahead && known > 0) {
+				const int lv = queued;
+				uint64_t bound = known;
+				for (int k = read; k < lv; k++) bound = std::min<uint64_t>(bound * fan, sc->qcap);
+				const uint32_t nb = (uint32_t)std::min<uint64_t>(bound, sc->qcap);
+				const uint32_t* nDev = lv == 0 ? nullptr : &L[lv - 1].next_count;
+				const bool packets = coherent(lv) && lv == 0;
+				rtk_intersect(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketNear : sc->maxBlocks, ln->ray[cur], nb, ln->hitq, &L[lv], nDev);
+				rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, nb, ln->ray[cur ^ 1], ln->surfq, ln->transq, &L[lv], sc->accum, aaSq, maxDepth,
+				          shadows, lv == 0 ? src.outHit : nullptr, src.outId, src.outT, pick, sc->texFix(*ln), nDev);
+				if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, nb, ln->ray[cur ^ 1], &L[lv], sc->accum, aaSq, maxDepth, pick);
+				seqOf[lv] = ++ln->reportSeq ? ln->reportSeq : ++ln->reportSeq;   // (never 0)
+				rtk_publish(st, &L[lv], ln->reportDev + lv, seqOf[lv]);
+				if (shadows) {
+					if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nb, sc->pointLights, sc->nPointLights, sc->accum, aaSq, &L[lv], true, sc->maxBlocksPacketShadow2);
+					for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, false, ln->surfq, nb, al.first, al.second, seed, sc->accum, aaSq, &L[lv], true);
+				}
+				if (int rcL = launchesOk()) return rcL;
+				cur ^= 1;
+				queued++;
+			}
+			if (read == queued) break;     // nothing in flight that the host has not seen
+			// the counts of the oldest level not yet read
+			RtLevelReport c;
+			if (int rcW = awaitReport(ln->report + read, seqOf[read], c)) return rcW;
+			nearRays += known;
+			nLevels++;
+			shadowRays += (uint64_t)std::min<uint32_t>(c.surf_count, sc->qcap) * sc->shadowRaysPerSurface;
+			if (c.overflow) overflow = true;
+			known = overflow ? 0 : std::min<uint32_t>(c.next_count, sc->qcap);
+			read++;
+			if (read > lastLevel) known = 0;
+			if (known == 0) break;         // whatever is still queued behind this level finds no items and leaves at once
+		}
+		if (overflow) return 1;
+		stats.rays_nearest += nearRays; stats.rays_shadow += shadowRays; stats.levels = std::max<uint64_t>(stats.levels, nLevels);
+		return RT_OK;
+	}
+
 	// Runs [r0, r0+cnt); on a queue overflow discards what the batch accumulated and re-runs it in two halves.
 	int batch(uint32_t r0, uint32_t cnt) {
 		const rt_stats saved = stats;
-		int rc = levels(r0, cnt);
+		int rc = canRunAhead() ? levelsAhead(r0, cnt) : levels(r0, cnt);
 		if (rc != 1) return rc;
 		stats = saved;
 		stats.batch_splits++;
@@ -890,6 +993,8 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	for (int32_t i = 0; i < s->n_materials; i++) {
 		const float* kt = s->materials[i].transmissive;
 		if (kt[0] != 0 || kt[1] != 0 || kt[2] != 0) sc->hasTransmissive = true;
+		const float* kr = s->materials[i].reflective;
+		if (kr[0] != 0 || kr[1] != 0 || kr[2] != 0) sc->hasReflective = true;
 	}
 
 	for (int64_t i = 0; i < s->n_tris && !sc->texelFix; i++) {
@@ -943,6 +1048,7 @@ void rt_scene_free(rt_scene* sc) {
 	if (sc->texHeads) (void)hipFree(sc->texHeads);
 	for (auto& ln : sc->lanes) {
 		if (ln.ctrHost) (void)hipHostFree(ln.ctrHost);
+		if (ln.report) (void)hipHostFree(ln.report);
 		for (auto& ev : ln.ev) if (ev) (void)hipEventDestroy(ev);
 		if (ln.stream) (void)hipStreamDestroy(ln.stream);
 	}

@@ -96,6 +96,9 @@ struct RtCounters {
 #endif
 };
 
+// what k_publish leaves in host memory for one level (Run::levelsAhead polls seq)
+struct RtLevelReport { uint32_t next_count, surf_count, overflow, seq; };
+
 // Texel state of textured triangles (texturemesh.cpp:49-50, objects.cpp:62-79): TextureTriangle::lightPoint writes the texel into the
 // triangle's own material and Object::lightPoint reads it back only after it has traced the reflected ray, so a hit whose reflection
 // subtree comes back to the same triangle is lit with the texel of the LAST hit on it.  A level is shaded before the levels below it
@@ -114,7 +117,10 @@ using rtd::DevScene;
 const char* rtk_take_launch_error();
 void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, int aaY, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq);
 void rtk_load_rays(hipStream_t st, const float* a, const float* b, uint32_t n, int bIsTarget, RtQueue rq, uint32_t pixBase);
-void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr);
+// nDev (may be null): where the kernels read the number of items themselves, n then being only a bound (a launch queued before the
+// host has seen the count)
+void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr,
+                   const uint32_t* nDev = nullptr);
 void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, uint8_t* hit, int32_t* id, float* t);
 // rt_trace_pick: where the shading and transmit kernels leave the events of the narration (null ev: no narration)
 struct RtPick { rt_pick_event* ev; uint32_t* count; uint32_t cap; };
@@ -122,14 +128,15 @@ void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint3
                   RtPick pick = RtPick{ nullptr, nullptr, 0 });
 void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
                uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick = RtPick{ nullptr, nullptr, 0 },
-               RtTexFix tex = RtTexFix{ nullptr, nullptr, 0 });
+               RtTexFix tex = RtTexFix{ nullptr, nullptr, 0 }, const uint32_t* nDev = nullptr);
 // after the last level of a batch: the corrections for `count` records, then the lists and the record counter are emptied again
 void rtk_texel_fix(hipStream_t st, const DevScene& S, bool csg, RtTexFix tex, uint32_t count, RtCounters* ctr, RtAccum A, uint32_t aaSq, uint32_t seed, bool apply);
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                       RtAccum A, uint32_t aaSq, RtCounters* ctr, bool countOnDevice = false, int maxBlocksPairs = 0);
 void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t samples, uint32_t seed,
-                     RtAccum A, uint32_t aaSq, RtCounters* ctr);
+                     RtAccum A, uint32_t aaSq, RtCounters* ctr, bool countOnDevice = false);
 void rtk_shadow_query(hipStream_t st, const DevScene& S, bool csg, const float* point, const float* lightPos, uint32_t n, uint8_t* lit, float* shadow);
 void rtk_resolve(hipStream_t st, RtAccum A, int W, int H, int tileRank, int tileRanks, uint32_t lp0, uint32_t count, uint32_t aaSq, int linear, float* rgb);
 void rtk_tiles_copy(hipStream_t st, const float* src, float* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode);
 void rtk_tiles_rgb8(hipStream_t st, const void* src, uint8_t* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode);
+void rtk_publish(hipStream_t st, const RtCounters* ctr, RtLevelReport* hostMapped, uint32_t seq);

@@ -817,7 +817,9 @@ __device__ __forceinline__ WorkPool firstPool(unsigned long long total) {
 	const unsigned long long b = (unsigned long long)waveNumber() * chunk;
 	WorkPool p;
 	p.chunk = chunk;
-	p.drained = false;
+	// Nothing beyond the statically numbered pieces: no wave needs to ask the cursor to find that out.  (A launch sized by a bound, or
+	// a small level of a deep ray tree, has thousands of waves and little work: each of them asking once is the stampede again.)
+	p.drained = total <= (unsigned long long)waveCount() * chunk;
 	p.next = (uint32_t)(b < total ? b : total);
 	p.end = (uint32_t)(b + chunk < total ? b + chunk : total);
 	if (p.end < p.next) p.end = p.next;
@@ -863,12 +865,21 @@ __global__ __launch_bounds__(kBlock) void k_load_rays(const float* a, const floa
 	qsu(rq, RQ_PATH, i, 1u);
 }
 
+// A launch queued before the host knows how many items the level before it produced gets a bound for its grid (nArg) and reads
+// the count itself (nDev: the previous level's append counter, capped by the bound, which is also the queue's capacity).
+__device__ __forceinline__ uint32_t deviceCount(uint32_t nArg, const uint32_t* nDev) {
+	if (!nDev) return nArg;
+	const uint32_t n = *nDev;
+	return n < nArg ? n : nArg;
+}
+
 // Persistent nearest-hit kernel: the grid is sized to fill the chip once; every wave keeps pulling rays (fetchWork)
 // and lanes whose ray has finished are refilled while the rest of the wave keeps walking, so one long ray does not
 // idle 63 lanes and the launch has no tail of half-empty waves.
 template <bool CSG, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
+__global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RtQueue rq, uint32_t nArg, const uint32_t* nDev, RtQueue hq, RtCounters* ctr) {
 	__shared__ int32_t stack[kStack][kBlock];
+	const uint32_t n = deviceCount(nArg, nDev);
 	uint32_t idx = kInactive;
 	WorkPool pool = firstPool(n);
 	Trav T;
@@ -919,6 +930,7 @@ __device__ __forceinline__ PacketFeed firstPackets(uint32_t nPackets) {
 }
 __device__ __forceinline__ uint32_t fetchPacket(PacketFeed& f, uint32_t* head, uint32_t nPackets) {
 	if (f.next == f.end) {
+		if ((unsigned long long)nPackets <= (unsigned long long)waveCount() * kPacketChunk) return kInactive;   // every packet was handed out statically
 		uint32_t k = 0;
 		if (__lane_id() == 0) k = atomicAdd(head, kPacketChunk);
 		const unsigned long long b = (unsigned long long)__builtin_amdgcn_readfirstlane(k) + (unsigned long long)waveCount() * kPacketChunk;
@@ -931,8 +943,9 @@ __device__ __forceinline__ uint32_t fetchPacket(PacketFeed& f, uint32_t* head, u
 
 // Nearest hit for coherent ray sets: one packet = 64 consecutive queue slots (an 8x8 pixel block of the tile order).
 template <bool CSG, bool COUNT>
-__global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_intersect_packet(DevScene S, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr, uint32_t groupStride) {
+__global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_intersect_packet(DevScene S, RtQueue rq, uint32_t nArg, const uint32_t* nDev, RtQueue hq, RtCounters* ctr, uint32_t groupStride) {
 	const uint32_t lane = __lane_id();
+	const uint32_t n = deviceCount(nArg, nDev);
 	const PacketLds ws = packetLdsInit(S);
 	// Hand-out order: groups of kPacketGroup neighbouring packets, the groups visited with a stride coprime to their
 	// number.  A frame has stretches of packets that cost nothing (sky: every ray misses the root box); handed out in
@@ -1075,10 +1088,12 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 // shade: everything Object::lightPoint does except the shadow rays
 // ---------------------------------------------------------------------------------------------------------
 template <bool CSG, bool PICK, bool TEXFIX>
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueue hq, uint32_t nArg, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
                                                   RtAccum A, uint32_t aaSq, int maxDepth, int wantSurfaces,
                                                   uint8_t* outHit, int32_t* outId, float* outT, RtPick pick, RtTexFix tex) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t n = deviceCount(nArg, nDev);
+	if (blockIdx.x * kBlock >= n) return;   // (workgroup-uniform: a launch sized by a bound leaves its surplus workgroups at once)
 	// every record is read at once (index clamped, result masked): one memory round trip instead of two
 	const uint32_t ic = i < n ? i : 0u;
 	uint32_t pixKey = qu(rq, RQ_PIX, ic), path = qu(rq, RQ_PATH, ic), prim = qu(hq, HQ_PRIM, ic);
@@ -1323,9 +1338,11 @@ __device__ __forceinline__ void pointLightGeometry(const rt_light& L, f3 p, f3& 
 }
 
 template <bool CSG, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
-                                                         RtAccum A, uint32_t aaSq, RtCounters* ctr) {
+__global__ __launch_bounds__(kBlock) void k_shadow_point(DevScene S, RtQueue sq, uint32_t nsurfArg, const int32_t* lightList, uint32_t nLights,
+                                                         RtAccum A, uint32_t aaSq, RtCounters* ctr, int countOnDevice) {
 	__shared__ int32_t stack[kStack][kBlock];
+	const uint32_t nsurf = countOnDevice ? deviceCount(nsurfArg, &ctr->surf_count) : nsurfArg;
+	if (nsurf == 0) return;
 	const unsigned long long total = (unsigned long long)nsurf * nLights;
 	uint32_t idx = kInactive;
 	WorkPool pool = firstPool(total);
@@ -1493,8 +1510,10 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW2_WAVES_PER_SIMD) void k_shadow_po
 // consecutive lanes (their rays leave the same point towards neighbouring targets), summed across lanes by a
 // segmented shuffle scan so each surface costs one atomic per wave instead of one per sample.
 template <bool CSG, bool COUNT>
-__global__ __launch_bounds__(kBlock, RT_AREA_WAVES_PER_SIMD) void k_shadow_area(DevScene S, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t seed,
-                                                        RtAccum A, uint32_t aaSq, RtCounters* ctr) {
+__global__ __launch_bounds__(kBlock, RT_AREA_WAVES_PER_SIMD) void k_shadow_area(DevScene S, RtQueue sq, uint32_t nsurfArg, int lightIndex, uint32_t seed,
+                                                        RtAccum A, uint32_t aaSq, RtCounters* ctr, int countOnDevice) {
+	const uint32_t nsurf = countOnDevice ? deviceCount(nsurfArg, &ctr->surf_count) : nsurfArg;
+	if ((unsigned long long)blockIdx.x * kBlock >= (unsigned long long)nsurf * (uint32_t)S.lights[lightIndex].samples) return;   // workgroup-uniform
 	const PacketLds ws = packetLdsInit(S);
 	const rt_light L = S.lights[lightIndex];
 	const uint32_t ns = (uint32_t)L.samples;
@@ -1724,6 +1743,18 @@ __global__ __launch_bounds__(kBlock) void k_tiles_rgb8(const void* src, uint8_t*
 	else { const float* f = static_cast<const float*>(src); for (int k = 0; k < 3; k++) dst[3 * out + k] = quantize8(f[3 * ((size_t)y * W + x) + k]); }
 }
 
+// The counts of a level, written straight into host memory (pinned, mapped) for the host loop that runs ahead of the GPU: one
+// 64-thread launch instead of a copy and an event in the stream, and the host sees them as soon as the store lands instead of
+// after a copy engine and an interrupt.  `seq` (never 0) goes last, behind a system-scope fence: the host polls it.
+__global__ __launch_bounds__(64) void k_publish(const RtCounters* ctr, RtLevelReport* host, uint32_t seq) {
+	if (threadIdx.x != 0) return;
+	host->next_count = ctr->next_count;
+	host->surf_count = ctr->surf_count;
+	host->overflow = ctr->overflow;
+	__threadfence_system();
+	__hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 inline unsigned gridFor(unsigned long long n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 // persistent kernels: enough workgroups to fill every CU once (the kernels loop over the work themselves)
 inline unsigned gridPersistent(unsigned long long n, int maxBlocks) { return (unsigned)std::min<unsigned long long>((n + kBlock - 1) / kBlock, (unsigned long long)maxBlocks); }
@@ -1791,36 +1822,36 @@ static uint32_t coprimeStride(uint32_t groups) {
 	while (gcd(s, groups) != 1) s++;
 	return s % groups ? s % groups : 1;
 }
-void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr) {
-	if (coherent) {
+void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr, const uint32_t* nDev) {
+	if (coherent) {   // (only ever with an exact n: the hand-out stride is computed from it)
 		const uint32_t stride = coprimeStride(((n + 63u) / 64u + kPacketGroup - 1u) / kPacketGroup);
-		if (csg) { if (count) RT_LAUNCH_PS((k_intersect_packet<true, true>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, hq, ctr, stride); else RT_LAUNCH_PS((k_intersect_packet<true, false>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, hq, ctr, stride); }
-		else { if (count) RT_LAUNCH_PS((k_intersect_packet<false, true>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, hq, ctr, stride); else RT_LAUNCH_PS((k_intersect_packet<false, false>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, hq, ctr, stride); }
+		if (csg) { if (count) RT_LAUNCH_PS((k_intersect_packet<true, true>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, nDev, hq, ctr, stride); else RT_LAUNCH_PS((k_intersect_packet<true, false>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, nDev, hq, ctr, stride); }
+		else { if (count) RT_LAUNCH_PS((k_intersect_packet<false, true>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, nDev, hq, ctr, stride); else RT_LAUNCH_PS((k_intersect_packet<false, false>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, nDev, hq, ctr, stride); }
 		return;
 	}
-	if (csg) { if (count) RT_LAUNCH_P((k_intersect<true, true>), n, maxBlocks, st, S, rq, n, hq, ctr); else RT_LAUNCH_P((k_intersect<true, false>), n, maxBlocks, st, S, rq, n, hq, ctr); }
-	else { if (count) RT_LAUNCH_P((k_intersect<false, true>), n, maxBlocks, st, S, rq, n, hq, ctr); else RT_LAUNCH_P((k_intersect<false, false>), n, maxBlocks, st, S, rq, n, hq, ctr); }
+	if (csg) { if (count) RT_LAUNCH_P((k_intersect<true, true>), n, maxBlocks, st, S, rq, n, nDev, hq, ctr); else RT_LAUNCH_P((k_intersect<true, false>), n, maxBlocks, st, S, rq, n, nDev, hq, ctr); }
+	else { if (count) RT_LAUNCH_P((k_intersect<false, true>), n, maxBlocks, st, S, rq, n, nDev, hq, ctr); else RT_LAUNCH_P((k_intersect<false, false>), n, maxBlocks, st, S, rq, n, nDev, hq, ctr); }
 }
 void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, uint8_t* hit, int32_t* id, float* t) {
 	RT_LAUNCH(k_export_hits, n, st, S, hq, n, hit, id, t);
 }
 void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
-               uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick, RtTexFix tex) {
+               uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick, RtTexFix tex, const uint32_t* nDev) {
 	if (pick.ev) {   // rt_trace_pick: the variants that narrate
 		if (tex.rec) {
-			if (csg) RT_LAUNCH((k_shade<true, true, true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
-			else RT_LAUNCH((k_shade<false, true, true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
-		} else if (csg) RT_LAUNCH((k_shade<true, true, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
-		else RT_LAUNCH((k_shade<false, true, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+			if (csg) RT_LAUNCH((k_shade<true, true, true>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+			else RT_LAUNCH((k_shade<false, true, true>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+		} else if (csg) RT_LAUNCH((k_shade<true, true, false>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+		else RT_LAUNCH((k_shade<false, true, false>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
 		return;
 	}
 	if (tex.rec) {   // scenes with reflective textured triangles
-		if (csg) RT_LAUNCH((k_shade<true, false, true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
-		else RT_LAUNCH((k_shade<false, false, true>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+		if (csg) RT_LAUNCH((k_shade<true, false, true>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+		else RT_LAUNCH((k_shade<false, false, true>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
 		return;
 	}
-	if (csg) RT_LAUNCH((k_shade<true, false, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
-	else RT_LAUNCH((k_shade<false, false, false>), n, st, S, rq, hq, n, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+	if (csg) RT_LAUNCH((k_shade<true, false, false>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+	else RT_LAUNCH((k_shade<false, false, false>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
 }
 void rtk_texel_fix(hipStream_t st, const DevScene& S, bool csg, RtTexFix tex, uint32_t count, RtCounters* ctr, RtAccum A, uint32_t aaSq, uint32_t seed, bool apply) {
 	if (!tex.rec || count == 0) return;
@@ -1869,14 +1900,15 @@ void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, b
 		else { if (count) RT_LAUNCH_PS((k_shadow_point_packet<false, true>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod, 0); else RT_LAUNCH_PS((k_shadow_point_packet<false, false>), pitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod, 0); }
 		return;
 	}
-	if (csg) { if (count) RT_LAUNCH_P((k_shadow_point<true, true>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_P((k_shadow_point<true, false>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
-	else { if (count) RT_LAUNCH_P((k_shadow_point<false, true>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); else RT_LAUNCH_P((k_shadow_point<false, false>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr); }
+	if (csg) { if (count) RT_LAUNCH_P((k_shadow_point<true, true>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); else RT_LAUNCH_P((k_shadow_point<true, false>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); }
+	else { if (count) RT_LAUNCH_P((k_shadow_point<false, true>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); else RT_LAUNCH_P((k_shadow_point<false, false>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); }
 }
 void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t samples, uint32_t seed,
-                     RtAccum A, uint32_t aaSq, RtCounters* ctr) {
+                     RtAccum A, uint32_t aaSq, RtCounters* ctr, bool countOnDevice) {
+	const int cod = countOnDevice ? 1 : 0;
 	const unsigned long long items = (unsigned long long)nsurf * samples;
-	if (csg) { if (count) RT_LAUNCH_S((k_shadow_area<true, true>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); else RT_LAUNCH_S((k_shadow_area<true, false>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); }
-	else { if (count) RT_LAUNCH_S((k_shadow_area<false, true>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); else RT_LAUNCH_S((k_shadow_area<false, false>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr); }
+	if (csg) { if (count) RT_LAUNCH_S((k_shadow_area<true, true>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr, cod); else RT_LAUNCH_S((k_shadow_area<true, false>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr, cod); }
+	else { if (count) RT_LAUNCH_S((k_shadow_area<false, true>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr, cod); else RT_LAUNCH_S((k_shadow_area<false, false>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr, cod); }
 }
 void rtk_shadow_query(hipStream_t st, const DevScene& S, bool csg, const float* point, const float* lightPos, uint32_t n, uint8_t* lit, float* shadow) {
 	if (csg) RT_LAUNCH((k_shadow_query<true>), n, st, S, point, lightPos, n, lit, shadow);
@@ -1890,4 +1922,7 @@ void rtk_tiles_copy(hipStream_t st, const float* src, float* dst, int W, int H, 
 }
 void rtk_tiles_rgb8(hipStream_t st, const void* src, uint8_t* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode) {
 	RT_LAUNCH(k_tiles_rgb8, count, st, src, dst, W, H, tileRank, tileRanks, count, mode);
+}
+void rtk_publish(hipStream_t st, const RtCounters* ctr, RtLevelReport* hostMapped, uint32_t seq) {
+	RT_LAUNCH_RAW(k_publish, dim3(1), dim3(64), 0, st, ctr, hostMapped, seq);
 }

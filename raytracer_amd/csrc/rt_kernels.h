@@ -59,6 +59,8 @@
 // starts), then per wave one 1 KB buffer per deeper treelet level, one more when the scene has external runs to stage,
 // and the stack
 #define RT_PACKET_WAVE_LDS_BYTES(levels, staging) ((((levels) > 1 ? (levels) - 1 : 0) + ((staging) ? 1 : 0)) * 1024 + RT_PACKET_STACK_BYTES)
+#define RT_COLD_FLOATS 16                                    /* per lane: two directions, two lengths, two attenuation colours (14 used) */
+#define RT_PACKET_COLD_BYTES (RT_COLD_FLOATS * 64 * 4)       /* per wave, k_shadow_point_packet2 only, behind the stack */
 #define RT_PACKET_LDS_BYTES(levels, staging) (1024 + (RT_BLOCK / 64) * RT_PACKET_WAVE_LDS_BYTES(levels, staging))
 
 // SoA queue: component c of slot i lives at f[c * cap + i]

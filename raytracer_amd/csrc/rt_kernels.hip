@@ -35,6 +35,13 @@
 
 using namespace rtd;
 
+#ifndef RT_SCHED_SPLIT
+#define RT_SCHED_SPLIT 0
+#endif
+#ifndef RT_ABLATE
+#define RT_ABLATE 0   /* diagnostic builds: bit 0 = walks without their triangle tests (tools/ab_libs.sh) */
+#endif
+
 namespace {
 
 constexpr int kBlock = RT_BLOCK;
@@ -480,18 +487,26 @@ struct PacketLds {
 	float4* treelet;            // [levels - 1 (+ 1)][64]: this wave's buffer per deeper treelet level, then the staging buffer
 	uint32_t (*stack)[8];       // [RT_PACKET_STACK_DEPTH] x 32 B: node, lane mask lo/hi, level (inner) or aux (leaf); the two-ray walk uses all 32 B
 	uint32_t staging;           // index of the staging buffer in treelet[]
+	float* cold;                // two-ray shadow walk only: [RT_COLD_FLOATS][64] per-lane state that only leaves touch (this lane's column)
 	__device__ __forceinline__ float4* level(uint32_t l) const { return l == 0 ? root : treelet + (l - 1u) * 64u; }
 };
+// Per-lane state of the two-ray shadow walk that only the leaves (and the rare exact box test) need -- the two directions, their
+// lengths, the two attenuation colours -- lives in LDS, one column per lane, and is loaded where it is used: 14 registers fewer are
+// live through the node steps, which is what decides how many waves a SIMD holds.  cold[k * 64] = value k of this lane.
+enum { COLD_DA = 0, COLD_DB = 3, COLD_LENA = 6, COLD_LENB = 7, COLD_SHA = 8, COLD_SHB = 11 };
+__device__ __forceinline__ f3 coldLd3(const float* cold, int k) { return mk3(cold[k * 64], cold[(k + 1) * 64], cold[(k + 2) * 64]); }
+__device__ __forceinline__ void coldSt3(float* cold, int k, f3 v) { cold[k * 64] = v.x; cold[(k + 1) * 64] = v.y; cold[(k + 2) * 64] = v.z; }
 extern __shared__ float4 packetLdsRaw[];
 // Carves up the workgroup's dynamic LDS (RT_PACKET_LDS_BYTES) and fetches the root treelet.  Ends with a barrier:
 // call it once, at the top of the kernel, from every thread.
-__device__ __forceinline__ PacketLds packetLdsInit(const DevScene& S) {
+__device__ __forceinline__ PacketLds packetLdsInit(const DevScene& S, bool withCold = false) {
 	PacketLds L;
-	const uint32_t perWave = RT_PACKET_WAVE_LDS_BYTES(S.treelet_levels, S.treelet_staging) / 16;
+	const uint32_t perWave = (RT_PACKET_WAVE_LDS_BYTES(S.treelet_levels, S.treelet_staging) + (withCold ? RT_PACKET_COLD_BYTES : 0)) / 16;
 	L.root = packetLdsRaw;
 	L.treelet = packetLdsRaw + 64 + (threadIdx.x >> 6) * perWave;
 	L.staging = S.treelet_levels > 1 ? (uint32_t)S.treelet_levels - 1u : 0u;
 	L.stack = reinterpret_cast<uint32_t (*)[8]>(L.treelet + (L.staging + (S.treelet_staging ? 1u : 0u)) * 64u);
+	L.cold = reinterpret_cast<float*>(L.stack + RT_PACKET_STACK_DEPTH) + (threadIdx.x & 63u);
 	if (threadIdx.x < 64 && S.treelet_root >= 0) L.root[threadIdx.x] = S.treelets[threadIdx.x];
 	__syncthreads();
 	return L;
@@ -499,7 +514,7 @@ __device__ __forceinline__ PacketLds packetLdsInit(const DevScene& S) {
 
 // One generic primitive (wave-uniform reference, record fetched from memory) for the lanes in `inSub`.
 template <bool ANYHIT, bool CSG, bool COUNT>
-__device__ __forceinline__ void packetPrim(const DevScene& S, Trav& T, bool inSub, uint32_t ref, uint32_t key) {
+__device__ __forceinline__ void packetPrim(const DevScene& S, Trav& T, bool inSub, uint32_t ref, uint32_t key, float* coldShadow = nullptr) {
 	if (inSub && (!ANYHIT || T.lit)) {
 		uint32_t tag = 0;
 		const float t = primHitUniform<CSG>(S, ref, T.e, T.d, tag);
@@ -508,7 +523,7 @@ __device__ __forceinline__ void packetPrim(const DevScene& S, Trav& T, bool inSu
 			if ((double)t > 1e-5 && (t < T.tmin || (t == T.tmin && key < T.bestKey))) { T.best = ref; T.bestTag = tag; T.tmin = t; T.bestKey = key; }
 		} else if (t < 1.0f && (double)(t * T.len) > 1e-5) {   // bvh.cpp:145-157
 			const float* kt = S.materials[primMaterial(S, ref)].transmissive;
-			if (!isZero3(kt)) T.shadow = T.shadow * ld3(kt);
+			if (!isZero3(kt)) { if (coldShadow) coldSt3(coldShadow, 0, coldLd3(coldShadow, 0) * ld3(kt)); else T.shadow = T.shadow * ld3(kt); }
 			else T.lit = false;
 		}
 	}
@@ -516,9 +531,12 @@ __device__ __forceinline__ void packetPrim(const DevScene& S, Trav& T, bool inSu
 
 // bvh.cpp:109-118 / 145-157 for a triangle whose record is already in registers (same in every lane)
 template <bool ANYHIT, bool COUNT>
-__device__ __forceinline__ void packetTri(const DevScene& S, Trav& T, bool inSub, float4 a, float4 b, float4 c, uint32_t index, int mat, uint32_t key) {
+__device__ __forceinline__ void packetTri(const DevScene& S, Trav& T, bool inSub, float4 a, float4 b, float4 c, uint32_t index, int mat, uint32_t key, float* coldShadow = nullptr) {
 	const bool active = inSub && (!ANYHIT || T.lit);
 	if (COUNT && active) T.cntPrims++;
+#if RT_ABLATE & 1
+	if (__float_as_uint(a.x) != 0x12345678u) return;   // diagnostic builds only: what the walks cost without their triangle tests
+#endif
 	// Most tests end at the plane: a shadow ray leaving a surface looks at the back of the neighbouring triangles.  The
 	// signs of the plane test's two dot products say so before the fp64 divide and the three edge tests, and when no lane
 	// of the packet is left the wave skips them (exact: triCandidate, rt_device.h).
@@ -533,7 +551,7 @@ __device__ __forceinline__ void packetTri(const DevScene& S, Trav& T, bool inSub
 			if ((double)t > 1e-5 && (t < T.tmin || (t == T.tmin && key < T.bestKey))) { T.best = RT_PRIM_REF(RT_PRIM_TRI, index); T.bestTag = 0; T.tmin = t; T.bestKey = key; }
 		} else if (t < 1.0f && (double)(t * T.len) > 1e-5) {
 			const float* kt = S.materials[mat].transmissive;
-			if (!isZero3(kt)) T.shadow = T.shadow * ld3(kt);
+			if (!isZero3(kt)) { if (coldShadow) coldSt3(coldShadow, 0, coldLd3(coldShadow, 0) * ld3(kt)); else T.shadow = T.shadow * ld3(kt); }
 			else T.lit = false;
 		}
 	}
@@ -698,6 +716,9 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 			bool h0A, h1A, h0B, h1B, a0A, a1A, a0B, a1B;
 			boxClassifyFlat(b0, A.e, A.inv, 1.0f, t, h0A, a0A);
 			boxClassifyFlat(b1, A.e, A.inv, 1.0f, t, h1A, a1A);
+#if RT_SCHED_SPLIT
+			__builtin_amdgcn_sched_barrier(0);
+#endif
 			boxClassifyFlat(b0, A.e, B.inv, 1.0f, t, h0B, a0B);
 			boxClassifyFlat(b1, A.e, B.inv, 1.0f, t, h1B, a1B);
 			h0A = h0A && inA && !A.special; h1A = h1A && inA && !A.special;
@@ -707,6 +728,7 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 			if (COUNT) { A.cntNodes += inA ? 1u : 0u; B.cntNodes += inB ? 1u : 0u; A.cntSteps++; }
 			if (cons) { h0A = h0A || a0A; h1A = h1A || a1A; h0B = h0B || a0B; h1B = h1B || a1B; }
 			else if (__ballot(a0A || a1A || a0B || a1B) != 0) {   // too close to call somewhere (rare): the reference's own arithmetic decides
+				A.d = coldLd3(L.cold, COLD_DA); B.d = coldLd3(L.cold, COLD_DB);
 				if (a0A) { const float tt = boxIntersect(b0, A.e, A.d, false); h0A = !(tt < 0 || tt > 1.0f); }
 				if (a1A) { const float tt = boxIntersect(b1, A.e, A.d, false); h1A = !(tt < 0 || tt > 1.0f); }
 				if (a0B) { const float tt = boxIntersect(b0, A.e, B.d, false); h0B = !(tt < 0 || tt > 1.0f); }
@@ -729,12 +751,14 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 			const bool longRun = (info >> 26) == 0u;
 			const uint32_t count = longRun ? info : info >> 26;
 			const uint32_t key0 = (uint32_t)~node + 1u;
+			// what only leaves need comes back from LDS (and is dead again after the leaf)
+			A.d = coldLd3(L.cold, COLD_DA); B.d = coldLd3(L.cold, COLD_DB); A.len = L.cold[COLD_LENA * 64]; B.len = L.cold[COLD_LENB * 64];
 			if (!longRun && (info & RT_TREELET_EMBED)) {
 				const float4* q = L.level((info >> 4) & 15u) + (info & 15u) * 4u;
 				for (uint32_t k = 0; k < count; k++, q += 4) {
 					const float4 a = q[0], b = q[1], c = q[2], d = q[3];
-					packetTri<true, COUNT>(S, A, inA, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), __float_as_uint(d.w));
-					packetTri<true, COUNT>(S, B, inB, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), __float_as_uint(d.w));
+					packetTri<true, COUNT>(S, A, inA, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), __float_as_uint(d.w), L.cold + COLD_SHA * 64);
+					packetTri<true, COUNT>(S, B, inB, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), __float_as_uint(d.w), L.cold + COLD_SHB * 64);
 				}
 			} else {
 				const uint32_t first = longRun ? (uint32_t)~node : info & (RT_TREELET_EMBED - 1u);
@@ -745,18 +769,19 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 					__builtin_amdgcn_wave_barrier();
 					for (uint32_t k = 0; k < nb; k++) {
 						const float4 a = buf[4 * k], b = buf[4 * k + 1], c = buf[4 * k + 2], d = buf[4 * k + 3];
-						packetTri<true, COUNT>(S, A, inA, a, b, c, first + k0 + k, __float_as_int(d.y), key0 + k0 + k);
-						packetTri<true, COUNT>(S, B, inB, a, b, c, first + k0 + k, __float_as_int(d.y), key0 + k0 + k);
+						packetTri<true, COUNT>(S, A, inA, a, b, c, first + k0 + k, __float_as_int(d.y), key0 + k0 + k, L.cold + COLD_SHA * 64);
+						packetTri<true, COUNT>(S, B, inB, a, b, c, first + k0 + k, __float_as_int(d.y), key0 + k0 + k, L.cold + COLD_SHB * 64);
 					}
 					__builtin_amdgcn_wave_barrier();
 				}
 			}
 		} else {
 			int32_t at = ~node;
+			A.d = coldLd3(L.cold, COLD_DA); B.d = coldLd3(L.cold, COLD_DB); A.len = L.cold[COLD_LENA * 64]; B.len = L.cold[COLD_LENB * 64];
 			for (;;) {
 				const uint32_t entry = *(cuint32*)(uintptr_t)(S.leaf_prims + at);
-				packetPrim<true, CSG, COUNT>(S, A, inA, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u);
-				packetPrim<true, CSG, COUNT>(S, B, inB, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u);
+				packetPrim<true, CSG, COUNT>(S, A, inA, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u, L.cold + COLD_SHA * 64);
+				packetPrim<true, CSG, COUNT>(S, B, inB, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u, L.cold + COLD_SHB * 64);
 				if (entry & RT_PRIM_LAST) break;
 				at++;
 			}
@@ -1454,7 +1479,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW2_WAVES_PER_SIMD) void k_shadow_po
                                                                  RtAccum A, uint32_t aaSq, RtCounters* ctr, int countOnDevice) {
 	const uint32_t nsurf = countOnDevice ? (ctr->surf_count < sq.cap ? ctr->surf_count : sq.cap) : nsurfArg;
 	const uint32_t lane = __lane_id();
-	const PacketLds ws = packetLdsInit(S);
+	const PacketLds ws = packetLdsInit(S, true);
 	const uint32_t totalPackets = ((nsurf + 63u) / 64u) * nPairs;
 	unsigned long long cn = 0, cp = 0, cs = 0;
 	PacketFeed feed = firstPackets(totalPackets);
@@ -1474,8 +1499,12 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW2_WAVES_PER_SIMD) void k_shadow_po
 			travInit<true>(S, TA, p, lightPos - p);   // bvh.cpp:124
 			pointLightGeometry(S.lights[lightB], p, Ld, lightPos);
 			travInit<true>(S, TB, p, lightPos - p);
+			coldSt3(ws.cold, COLD_DA, TA.d); coldSt3(ws.cold, COLD_DB, TB.d);
+			ws.cold[COLD_LENA * 64] = TA.len; ws.cold[COLD_LENB * 64] = TB.len;
 		}
+		coldSt3(ws.cold, COLD_SHA, mk3(1.0f, 1.0f, 1.0f)); coldSt3(ws.cold, COLD_SHB, mk3(1.0f, 1.0f, 1.0f));
 		packetTraverse2<CSG, COUNT>(S, ws, TA, TB, alive, alive);
+		TA.shadow = coldLd3(ws.cold, COLD_SHA); TB.shadow = coldLd3(ws.cold, COLD_SHB);
 		q = fetchPacket(feed, &ctr->head_shadow, totalPackets);
 		if (COUNT) { cn += TA.cntNodes + TB.cntNodes; cp += TA.cntPrims + TB.cntPrims; cs += 2u * TA.cntSteps; }   // a step of the two-ray walk serves two rays per lane
 		if (alive && (TA.lit || TB.lit)) {
@@ -1890,8 +1919,8 @@ void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, b
 			if (csg) { if (count) RT_LAUNCH_PS((k_shadow_point_packet<true, true>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); else RT_LAUNCH_PS((k_shadow_point_packet<true, false>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); }
 			else { if (count) RT_LAUNCH_PS((k_shadow_point_packet<false, true>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); else RT_LAUNCH_PS((k_shadow_point_packet<false, false>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); }
 		}
-		if (csg) { if (count) RT_LAUNCH_PS((k_shadow_point_packet2<true, true>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet2<true, false>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); }
-		else { if (count) RT_LAUNCH_PS((k_shadow_point_packet2<false, true>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet2<false, false>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); }
+		if (csg) { if (count) RT_LAUNCH_PS((k_shadow_point_packet2<true, true>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S) + (RT_BLOCK / 64) * RT_PACKET_COLD_BYTES, st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet2<true, false>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S) + (RT_BLOCK / 64) * RT_PACKET_COLD_BYTES, st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); }
+		else { if (count) RT_LAUNCH_PS((k_shadow_point_packet2<false, true>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S) + (RT_BLOCK / 64) * RT_PACKET_COLD_BYTES, st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet2<false, false>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S) + (RT_BLOCK / 64) * RT_PACKET_COLD_BYTES, st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); }
 		return;
 	}
 	if (coherent) {

@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include "rt_scene.h"
 #include "csg_sort.h"
+#include "libm_restate.h"
 
 namespace rtd {
 
@@ -561,8 +562,9 @@ __device__ __forceinline__ int f2i(float v) {
 __device__ inline f3 sphereNormal(const DevScene& S, const rt_sphere& s, f3 hp) {
 	f3 trueNormal = normalize(hp - ld3(s.center));
 	if (s.bump_tex < 0) return trueNormal;
-	float u = (float)(0.5 - (double)atan2f(-trueNormal.z, -trueNormal.x) / (2 * RTD_PI));
-	float v = (float)(0.5 - (double)asinf(trueNormal.y) / RTD_PI);
+	// glibc's atan2f / asinf bit for bit (libm_restate.h): the texel indices below are truncations of u * width, v * height
+	float u = (float)(0.5 - (double)rt_atan2f(-trueNormal.z, -trueNormal.x) / (2 * RTD_PI));
+	float v = (float)(0.5 - (double)rt_asinf(trueNormal.y) / RTD_PI);
 	const int height = S.textures[s.bump_tex].height, width = S.textures[s.bump_tex].width;
 	float value = float(texel(S, s.bump_tex, f2i(u * width), f2i(v * height))[0]) / 255;
 	float value_u = float(texel(S, s.bump_tex, f2i(u * width + 1) % width, f2i(v * height))[0]) / 255;

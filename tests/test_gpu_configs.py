@@ -63,10 +63,8 @@ def test_c2_full_size_vs_compiled_reference(c2):
     assert np.array_equal(r["hit"], g["hit"]) and np.array_equal(r["id"], g["id"]) and np.array_equal(bits(r["t"]), bits(g["t"]))
     assert sc.last_stats["rays_nearest"] == int(g["rays_nearest"]) and sc.last_stats["rays_shadow"] == int(g["rays_shadow"])
     d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(g["rgb"]).astype(int)).max(axis=1)
-    print(f"{int((d8 > 1).sum())} of {n} pixels beyond 1/255")
-    assert (d8 > 1).mean() < 2e-3
-    on_mesh = g["id"] < flat.info.n_objects - 2          # the two spheres were loaded last
-    assert d8[on_mesh & (g["hit"] != 0)].max() <= 1
+    # the bump-mapped spheres pick their texels with glibc's atan2f / asinf restated on the device (libm_restate.h): no pixel is off
+    assert int((d8 > 1).sum()) == 0, f"{int((d8 > 1).sum())} of {n} pixels beyond 1/255"
     a = sc.shadow_batch(g["shd_p"], g["shd_l"])
     assert np.array_equal(a["lit"], g["shd_lit"].astype(np.uint8))
     # the frame path (packets, lanes) on the same camera
@@ -88,10 +86,7 @@ def test_c2_1080p_sampled_rays_vs_oracle(c2):
     assert np.array_equal(r["hit"], o["hit"]) and np.array_equal(r["id"], o["id"])
     assert np.array_equal(bits(r["t"]), bits(o["t"]))
     d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(o["rgb"]).astype(int)).max(axis=1)
-    # bump-mapped spheres read a texel chosen by int(u*W) with u from atan2f/asinf: device libm may land on the neighbouring texel
-    assert (d8 > 1).mean() < 2e-3, f"{(d8 > 1).sum()} of {len(pick)} sampled pixels differ by more than 1/255"
-    on_mesh = o["id"] < flat.info.n_objects - 2          # the two spheres were loaded last
-    assert d8[on_mesh].max() <= 1
+    assert int((d8 > 1).sum()) == 0, f"{(d8 > 1).sum()} of {len(pick)} sampled pixels differ by more than 1/255"
 
 
 def test_c2_1080p_frame_properties(c2):
@@ -124,7 +119,26 @@ def test_c2_ray_counts_vs_oracle_reduced_frame(c2):
     ref, nn, ns = oracle.render(flat, cam, W, H, seed=1, threads=8)
     assert sc.last_stats["rays_nearest"] == nn and sc.last_stats["rays_shadow"] == ns
     d8 = np.abs(rgb8(img).astype(int) - rgb8(ref).astype(int)).max(axis=2)
-    assert (d8 > 1).mean() < 2e-3
+    assert int((d8 > 1).sum()) == 0
+
+
+def test_c2_bump_spheres_every_pixel_of_the_1080p_frame_vs_oracle(c2):
+    """Every 1080p pixel whose primary ray hits one of the two bump-mapped spheres (the only surfaces whose shading goes through a
+    truncated transcendental, bump.cpp:14-23), device against the oracle: the measured number of pixels beyond 1/255 is zero."""
+    flat, sc = c2
+    W, H = 1920, 1080
+    cam = rt.Camera(flat.fov, W, H, eye=(0, 1.5, 1.0), rot_x=-0.3)
+    s = primary_targets_np(cam, W, H)
+    e = np.tile(np.array(cam.c.eye[:], np.float32), (W * H, 1))
+    ids = sc.intersect_batch(e, s - e)["id"]
+    on_sphere = np.flatnonzero(ids >= flat.info.n_objects - 2)          # the two spheres were loaded last
+    assert len(on_sphere) > 20000
+    r = sc.trace_batch(e[on_sphere], s[on_sphere])
+    o = oracle.trace_batch(flat, e[on_sphere], s[on_sphere], seed=1, threads=8)
+    assert np.array_equal(r["id"], o["id"]) and np.array_equal(bits(r["t"]), bits(o["t"]))
+    d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(o["rgb"]).astype(int)).max(axis=1)
+    print(f"{len(on_sphere)} bump-sphere pixels at 1080p, {int((d8 > 1).sum())} beyond 1/255, max float difference {np.abs(r['rgb'] - o['rgb']).max():.2e}")
+    assert int((d8 > 1).sum()) == 0
 
 
 def _against_dump(sc, g, rgb_exact=True):
@@ -290,6 +304,87 @@ def test_c4_area_lights_64_samples(tmp_path):
     # the frame path (packets of 64 samples per surface) agrees with the batch path
     img = sc.render(W, H, camera=cam, seed=99)
     assert np.abs(img.reshape(-1, 3) - r["rgb"]).max() < 1e-6
+    sc.close()
+
+
+def test_c4_full_size_frame_properties(tmp_path):
+    """C4 at BASELINE's size -- 1920x1080, two area lights of 64 samples -- through size-independent properties: the frame is the
+    same bits run to run, the tiles of 2 and of 4 shards compose to it, and every hit costs exactly 128 shadow rays."""
+    import torch
+    flat = rt.FlatScene.from_json(scenes.c4_scene(str(tmp_path), samples=64))
+    sc = rt.Scene(flat, 0)
+    W, H = 1920, 1080
+    cam = rt.Camera(flat.fov, W, H)
+    a = torch.zeros(H, W, 3, device="cuda")
+    st = sc.render_into(a.data_ptr(), W, H, camera=cam, seed=7)
+    b = torch.zeros(H, W, 3, device="cuda")
+    sc.render_into(b.data_ptr(), W, H, camera=cam, seed=7)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    s = primary_targets_np(cam, W, H)
+    hits = int(sc.intersect_batch(np.zeros((W * H, 3), np.float32), s)["hit"].sum())
+    assert st["rays_nearest"] == W * H and st["rays_shadow"] == 128 * hits and st["levels"] == 1
+    for shards in (2, 4):
+        parts = torch.zeros(H, W, 3, device="cuda")
+        rays = 0
+        for k in range(shards):
+            rays += sc.render_into(parts.data_ptr(), W, H, camera=cam, seed=7, tile_rank=k, tile_ranks=shards)["rays_shadow"]
+        assert torch.equal(parts.view(torch.int32), a.view(torch.int32)) and rays == st["rays_shadow"]
+    c = torch.zeros(H, W, 3, device="cuda")
+    sc.render_into(c.data_ptr(), W, H, camera=cam, seed=8)                 # another seed: other sample points, another image
+    assert not torch.equal(a, c) and float((a - c).abs().mean()) < 0.02
+    sc.close()
+
+
+def test_scene_l_at_640x480_counts_the_hidden_state_pixels(gpu_scenes, flat_scenes):
+    """Bundled scene l at the reference's own 640x480 against the compiled reference's dump.  Two pixels of the reference depend on the hit
+    cache a mesh was left with by exit searches of EARLIER pixels (objects.cpp:123-125): the device, which has no
+    state across pixels, may differ there and nowhere else."""
+    import os
+    from conftest import GOLD
+    g = dict(np.load(os.path.join(GOLD, "ref_l_640.npz")))
+    fs, sc = flat_scenes("l"), gpu_scenes("l")
+    cam = rt.Camera(fs.fov, 640, 480)
+    img = sc.render(640, 480, camera=cam)
+    st = dict(sc.last_stats)
+    got = rt.quantize_rgb8(img)[::-1].reshape(-1, 3)          # back to row 0 = bottom, the dump's order
+    off = (np.abs(got.astype(int) - g["rgb8"].astype(int)).max(axis=1) > 1)
+    print(f"scene l 640x480: {int(off.sum())} of 307200 pixels beyond 1/255 of the compiled reference (hidden-state pixels: at most 2)")
+    assert int(off.sum()) <= 2
+    assert abs(st["rays_nearest"] - int(g["rays_nearest"])) <= 4 and abs(st["rays_shadow"] - int(g["rays_shadow"])) <= 8
+    s = primary_targets_np(cam, 640, 480)
+    r = sc.intersect_batch(np.zeros((640 * 480, 3), np.float32), s)
+    assert np.array_equal(r["id"].astype(np.int16), g["id"])
+
+
+def test_c5_full_size_4k_16spp_properties(tmp_path):
+    """C5 at BASELINE's size -- 4 999 122 triangles, 3840x2160, 4x4 samples per pixel -- through size-independent properties: ray counts
+    (16 primary rays per pixel, two shadow rays per hit), the same bits run to run, and the tiles of 8 shards compose to the frame."""
+    import torch
+    flat = rt.FlatScene.from_json(scenes.c5_scene(str(tmp_path), grid=1581))
+    sc = rt.Scene(flat, 0)
+    W, H = 3840, 2160
+    cam = rt.Camera(flat.fov, W, H, eye=(0, 1.5, 1.0), rot_x=-0.3)
+    a = torch.zeros(H, W, 3, device="cuda")
+    st = sc.render_into(a.data_ptr(), W, H, aa=(4, 4), camera=cam)
+    assert st["rays_nearest"] == 16 * W * H and st["rays_shadow"] % 2 == 0 and 0 < st["rays_shadow"] <= 2 * st["rays_nearest"]
+    parts = torch.zeros(H, W, 3, device="cuda")
+    rays_n = rays_s = 0
+    for k in range(8):
+        p = sc.render_into(parts.data_ptr(), W, H, aa=(4, 4), camera=cam, tile_rank=k, tile_ranks=8)
+        rays_n += p["rays_nearest"]; rays_s += p["rays_shadow"]
+    assert torch.equal(parts.view(torch.int32), a.view(torch.int32))         # 8-shard composition, and with it run-to-run determinism
+    assert rays_n == st["rays_nearest"] and rays_s == st["rays_shadow"]
+    # the 16 samples of a pixel average to what 16 single-sample frames shifted by the sub-pixel offsets give: checked on the supersampling
+    # identity of a coarse frame instead (cheap): a 4x4-sample frame at W/4 is the box filter of a 1-sample frame at W whose pixel centres
+    # are the sub-pixel positions
+    w4, h4 = W // 4, H // 4
+    cam4 = rt.Camera(flat.fov, w4, h4, eye=(0, 1.5, 1.0), rot_x=-0.3)
+    coarse = torch.zeros(h4, w4, 3, device="cuda")
+    sc.render_into(coarse.data_ptr(), w4, h4, aa=(4, 4), camera=cam4)
+    fine = torch.zeros(H, W, 3, device="cuda")
+    sc.render_into(fine.data_ptr(), W, H, camera=cam)
+    box = fine.view(h4, 4, w4, 4, 3).mean(dim=(1, 3))
+    assert float((box - coarse).abs().max()) < 2e-6
     sc.close()
 
 

@@ -1,11 +1,11 @@
-// libm_restate.h -- glibc's atan2f and asinf, restated operation for operation.
+// glibc_math.h -- glibc's atan2f and asinf, restated operation for operation.
 //
 // BumpSphere::getNormal (bump.cpp:14-23) picks its bump-map texels by int(u * width), int(v * height) with u from atan2f and v from
 // asinf (the float overloads: the arguments are floats).  The parity definition is the reference built against glibc (SURVEY.md
 // section 8c), and the device's own atan2f / asinf differ from glibc's in the last bits often enough to land 0.1 % of the pixels of
 // a bump-mapped sphere on the neighbouring texel.  These are glibc 2.35's algorithms (sysdeps/ieee754/flt-32/e_atan2f.c, s_atanf.c,
 // e_asinf.c: the fdlibm float kernels; no FMA variants exist for them), which on correctly rounded +, -, *, /, sqrt without
-// contraction -- what this library is compiled for -- give the same bits on the device as in glibc.  tests/test_libm_restate.py
+// contraction -- what this library is compiled for -- give the same bits on the device as in glibc.  tests/test_glibc_math.py
 // compiles this header with g++ and compares it with the host's libm on 20 M random arguments and on every float in [-1, 1].
 #pragma once
 #include <stdint.h>

@@ -11,7 +11,7 @@
 #include <stdint.h>
 #include "rt_scene.h"
 #include "csg_sort.h"
-#include "libm_restate.h"
+#include "glibc_math.h"
 
 namespace rtd {
 
@@ -562,7 +562,7 @@ __device__ __forceinline__ int f2i(float v) {
 __device__ inline f3 sphereNormal(const DevScene& S, const rt_sphere& s, f3 hp) {
 	f3 trueNormal = normalize(hp - ld3(s.center));
 	if (s.bump_tex < 0) return trueNormal;
-	// glibc's atan2f / asinf bit for bit (libm_restate.h): the texel indices below are truncations of u * width, v * height
+	// glibc's atan2f / asinf bit for bit (glibc_math.h): the texel indices below are truncations of u * width, v * height
 	float u = (float)(0.5 - (double)rt_atan2f(-trueNormal.z, -trueNormal.x) / (2 * RTD_PI));
 	float v = (float)(0.5 - (double)rt_asinf(trueNormal.y) / RTD_PI);
 	const int height = S.textures[s.bump_tex].height, width = S.textures[s.bump_tex].width;

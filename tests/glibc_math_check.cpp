@@ -1,11 +1,11 @@
-// tests/libm_restate_check.cpp -- rt_atan2f / rt_asinf (raytracer_amd/csrc/libm_restate.h, what the device evaluates bump-map coordinates
+// tests/glibc_math_check.cpp -- rt_atan2f / rt_asinf (raytracer_amd/csrc/glibc_math.h, what the device evaluates bump-map coordinates
 // with) against the host's libm (glibc: the library the compiled reference calls, bump.cpp:14-15), bit for bit.  Test infrastructure.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include "libm_restate.h"
+#include "glibc_math.h"
 static uint32_t bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 int main(int argc, char** argv) {
 	const long total = argc > 1 ? atol(argv[1]) : 20000000;

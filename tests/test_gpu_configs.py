@@ -63,7 +63,7 @@ def test_c2_full_size_vs_compiled_reference(c2):
     assert np.array_equal(r["hit"], g["hit"]) and np.array_equal(r["id"], g["id"]) and np.array_equal(bits(r["t"]), bits(g["t"]))
     assert sc.last_stats["rays_nearest"] == int(g["rays_nearest"]) and sc.last_stats["rays_shadow"] == int(g["rays_shadow"])
     d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(g["rgb"]).astype(int)).max(axis=1)
-    # the bump-mapped spheres pick their texels with glibc's atan2f / asinf restated on the device (libm_restate.h): no pixel is off
+    # the bump-mapped spheres pick their texels with glibc's atan2f / asinf restated on the device (glibc_math.h): no pixel is off
     assert int((d8 > 1).sum()) == 0, f"{int((d8 > 1).sum())} of {n} pixels beyond 1/255"
     a = sc.shadow_batch(g["shd_p"], g["shd_l"])
     assert np.array_equal(a["lit"], g["shd_lit"].astype(np.uint8))

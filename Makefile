@@ -12,7 +12,7 @@ LIB      := raytracer_amd/lib/libraytracer_amd.so
 CXXFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -Wall -Iinclude -I$(CSRC)
 HIPFLAGS := --offload-arch=$(ARCH) -std=c++17 -O3 -ffp-contract=off -fPIC -Iinclude -I$(CSRC) -Wno-unused-result
 
-HOST_SRCS := $(CSRC)/host/scene_loader.cpp $(CSRC)/host/host_api.cpp $(CSRC)/host/bmp_io.cpp $(CSRC)/host/raytracer_api.cpp
+HOST_SRCS := $(CSRC)/host/scene_loader.cpp $(CSRC)/host/host_api.cpp $(CSRC)/host/bmp_io.cpp $(CSRC)/host/raytracer_api.cpp $(CSRC)/host/view.cpp
 HIP_SRCS  := $(CSRC)/rt_kernels.hip $(CSRC)/rt_capi_device.hip
 HOST_OBJS := $(patsubst $(CSRC)/host/%.cpp,$(OBJ)/host_%.o,$(HOST_SRCS))
 HIP_OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJ)/hip_%.o,$(HIP_SRCS))
@@ -20,7 +20,7 @@ HIP_OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJ)/hip_%.o,$(HIP_SRCS))
 .PHONY: all lib oracle cli clean prof
 all: lib cli oracle
 lib: $(LIB)
-cli: raytracer_amd/bin/rt_render
+cli: raytracer_amd/bin/rt_render raytracer_amd/bin/rt_view
 oracle:
 	$(MAKE) -C oracle restate
 
@@ -34,6 +34,9 @@ $(LIB): $(HOST_OBJS) $(HIP_OBJS)
 	@mkdir -p $(dir $@)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 raytracer_amd/bin/rt_render: $(CSRC)/host/render_cli.cpp $(LIB)
+	@mkdir -p $(dir $@)
+	$(CXX) $(CXXFLAGS) -o $@ $< -Lraytracer_amd/lib -lraytracer_amd -Wl,-rpath,'$$ORIGIN/../lib'
+raytracer_amd/bin/rt_view: $(CSRC)/host/view_cli.cpp $(LIB)
 	@mkdir -p $(dir $@)
 	$(CXX) $(CXXFLAGS) -o $@ $< -Lraytracer_amd/lib -lraytracer_amd -Wl,-rpath,'$$ORIGIN/../lib'
 # instrumented build (per-phase shader-clock sums in the packet kernels, printed when RT_PROF_PRINT is set); use through RT_LIB_PATH

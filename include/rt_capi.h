@@ -203,6 +203,34 @@ int rt_tiles_pack_rgb8(rt_scene* scene, const float* frame_dev, uint8_t* packed_
 int rt_tiles_unpack_rgb8(rt_scene* scene, const uint8_t* packed_dev, uint8_t* frame8_dev, int width, int height, int tile_rank, int tile_ranks, void* stream);
 int rt_tiles_quantize_rgb8(rt_scene* scene, const float* frame_dev, uint8_t* frame8_dev, int width, int height, int tile_rank, int tile_ranks, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * The reference's interactive front end without its window (q1.cpp:23-29, 107-288).
+ * A view holds what the GLUT callbacks keep in globals: eye, rotationX / rotationY, the antialias flag, the window size, and the
+ * camera basis of the frame last displayed (which is what the movement keys move along, as in the reference).
+ *   rt_view_key       keyboard() q1.cpp:179-247: w s a d (move), q e r f (turn, r / f limited to +-pi/2), t g (up / down), l (4x
+ *                     supersampling on / off), p (prints camera and facing), space, Escape.  Returns 1 if the key starts a new frame
+ *                     (drawing_y = 0), 0 if not, -1 for Escape (the reference exits); what the reference prints goes to `text`.
+ *   rt_view_reshape   reshape() q1.cpp:278-288
+ *   rt_view_render    display() q1.cpp:107-175 as ONE frame on the GPU: setFacing(), then every pixel (4 s_aa samples with `l` on);
+ *                     rgb_dev as in rt_render
+ *   rt_view_scanline  the row display() draws in pass number `pass` (every 16th row, 16 sweeps: q1.cpp:124), for a front end that
+ *                     reveals the finished frame in the reference's order
+ *   rt_view_click     mouse() q1.cpp:251-269: left button down at window position (x, y from the top): the narration of the picked
+ *                     ray followed by the HIT / MISS lines, as the reference prints them
+ *   rt_view_camera / rt_view_state   the pose the next frame will use / the raw state
+ * `scene` may be NULL for a view that is only asked about keys and poses (no GPU needed). */
+typedef struct rt_view rt_view;
+int rt_view_create(rt_scene* scene, double fov, int width, int height, rt_view** out);
+void rt_view_free(rt_view* view);
+int rt_view_key(rt_view* view, unsigned char key, char* text, size_t cap, size_t* text_len);
+int rt_view_reshape(rt_view* view, int width, int height);
+int rt_view_camera(const rt_view* view, rt_camera* camera, int* aa);
+int rt_view_state(const rt_view* view, float eye[3], float* rotation_x, float* rotation_y, int* width, int* height, int* needs_redraw);
+int rt_view_render(rt_view* view, float* rgb_dev, void* stream, rt_stats* stats);
+int rt_view_render_host(rt_view* view, float* rgb_host, rt_stats* stats);   /* convenience, like rt_render_host */
+int rt_view_scanline(int height, int pass);
+int rt_view_click(rt_view* view, int x, int y_from_top, char* text, size_t cap, size_t* text_len);
+
 const char* rt_last_error(void);
 const char* rt_version(void);
 

@@ -9,6 +9,6 @@ include/rt_capi.h; the work is done by hand-written HIP kernels (csrc/rt_kernels
     lit, shadow = rt.shadowRay(p, light)    # raytracer.cpp:111
     frame = rt.current_scene().render(640, 480)   # display()'s pixel loop, q1.cpp:130-147
 """
-from .api import (FlatScene, Scene, Camera, choose_scene, current_scene, trace, shadowRay, fov, background_colour,  # noqa: F401
+from .api import (FlatScene, Scene, Camera, View, choose_scene, current_scene, trace, shadowRay, fov, background_colour,  # noqa: F401
                   write_bmp, quantize_rgb8, device_count)
 from .capi import RtError, MAX_REFLECTIONS, RT_FLAG_COUNTERS, RT_FLAG_TIME_KERNELS  # noqa: F401

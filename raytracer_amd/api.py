@@ -194,6 +194,78 @@ class Scene:
         check(capi.load().rt_tiles_unpack(self._h, C.c_void_p(packed_ptr), C.c_void_p(frame_ptr), width, height, tile_rank, tile_ranks, C.c_void_p(stream or 0)))
 
 
+class View:
+    """The reference's interactive front end without its window (rt_view_*, q1.cpp:107-288): keys move the camera, render() is display()."""
+
+    def __init__(self, scene=None, fov=None, width=512, height=512):
+        self.scene = scene
+        h = C.c_void_p()
+        f = float(fov if fov is not None else (scene.flat.fov if scene is not None else 60.0))
+        check(capi.load().rt_view_create(scene._h if scene is not None else None, f, int(width), int(height), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            capi.load().rt_view_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def key(self, key):
+        """keyboard(key): returns (result, text) -- 1 new frame, 0 none, -1 Escape; text = what the reference prints."""
+        buf = C.create_string_buffer(512)
+        n = C.c_size_t(0)
+        k = key if isinstance(key, int) else ord(key)
+        rc = capi.load().rt_view_key(self._h, k, buf, 512, C.byref(n))
+        return rc, buf.value.decode()
+
+    def keys(self, text):
+        return [self.key(ch) for ch in text]
+
+    def reshape(self, width, height):
+        check(capi.load().rt_view_reshape(self._h, int(width), int(height)))
+
+    def camera(self):
+        cam = Camera.__new__(Camera)
+        cam.c = rt_camera()
+        aa = C.c_int(1)
+        check(capi.load().rt_view_camera(self._h, C.byref(cam.c), C.byref(aa)))
+        st = self.state()
+        cam.width, cam.height = st["width"], st["height"]
+        return cam, int(aa.value)
+
+    def state(self):
+        eye = (C.c_float * 3)()
+        rx, ry, w, h, d = C.c_float(), C.c_float(), C.c_int(), C.c_int(), C.c_int()
+        check(capi.load().rt_view_state(self._h, eye, C.byref(rx), C.byref(ry), C.byref(w), C.byref(h), C.byref(d)))
+        return dict(eye=np.array(eye[:], np.float32), rotation_x=float(rx.value), rotation_y=float(ry.value), width=int(w.value), height=int(h.value),
+                    needs_redraw=bool(d.value))
+
+    def render_into(self, frame_dev_ptr, stream=None):
+        st = rt_stats()
+        check(capi.load().rt_view_render(self._h, C.c_void_p(frame_dev_ptr), C.c_void_p(stream or 0), C.byref(st)))
+        return st.as_dict()
+
+    def render(self):
+        """display(): the frame as float32 [H, W, 3] on the host, row 0 = bottom."""
+        st0 = self.state()
+        out = np.empty((st0["height"], st0["width"], 3), np.float32)
+        st = rt_stats()
+        check(capi.load().rt_view_render_host(self._h, ptr(out), C.byref(st)))
+        self.last_stats = st.as_dict()
+        return out
+
+    @staticmethod
+    def scanline(height, k):
+        return int(capi.load().rt_view_scanline(int(height), int(k)))
+
+    def click(self, x, y_from_top):
+        buf = C.create_string_buffer(1 << 16)
+        n = C.c_size_t(0)
+        check(capi.load().rt_view_click(self._h, int(x), int(y_from_top), buf, 1 << 16, C.byref(n)))
+        return buf.value.decode()
+
+
 def _tiles_rgb8(name):
     def call(self, src_ptr, dst_ptr, width, height, tile_rank, tile_ranks, stream=None):
         check(getattr(capi.load(), name)(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), width, height, tile_rank, tile_ranks, C.c_void_p(stream or 0)))

@@ -21,7 +21,8 @@ SYMBOLS = [
     "rt_load_scene_json", "rt_load_scene_json_text", "rt_flat_scene_save", "rt_flat_scene_load", "rt_flat_scene_free",
     "rt_camera_setup", "rt_write_bmp", "rt_quantize_rgb8", "rt_device_count", "rt_scene_upload", "rt_scene_free",
     "rt_render", "rt_render_submit", "rt_render_wait", "rt_render_host", "rt_trace_batch", "rt_trace_pick", "rt_pick_narration", "rt_intersect_batch", "rt_intersect_batch_static", "rt_shadow_batch", "rt_tiles_merge",
-    "rt_tiles_count", "rt_tiles_pack", "rt_tiles_unpack", "rt_tiles_pack_rgb8", "rt_tiles_unpack_rgb8", "rt_tiles_quantize_rgb8", "rt_last_error", "rt_version",
+    "rt_tiles_count", "rt_tiles_pack", "rt_tiles_unpack", "rt_tiles_pack_rgb8", "rt_tiles_unpack_rgb8", "rt_tiles_quantize_rgb8", "rt_view_create", "rt_view_free", "rt_view_key", "rt_view_reshape", "rt_view_camera", "rt_view_state", "rt_view_render", "rt_view_render_host", "rt_view_scanline", "rt_view_click",
+    "rt_last_error", "rt_version",
 ]
 
 
@@ -108,6 +109,17 @@ def load():
     for name in ("rt_tiles_pack", "rt_tiles_unpack", "rt_tiles_merge", "rt_tiles_pack_rgb8", "rt_tiles_unpack_rgb8", "rt_tiles_quantize_rgb8"):
         getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.rt_tiles_count.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.rt_view_create.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.rt_view_free.argtypes = [C.c_void_p]
+    lib.rt_view_free.restype = None
+    lib.rt_view_key.argtypes = [C.c_void_p, C.c_ubyte, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.rt_view_reshape.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.rt_view_camera.argtypes = [C.c_void_p, C.POINTER(rt_camera), C.POINTER(C.c_int)]
+    lib.rt_view_state.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.rt_view_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]
+    lib.rt_view_render_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]
+    lib.rt_view_scanline.argtypes = [C.c_int, C.c_int]
+    lib.rt_view_click.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.rt_write_bmp.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
     lib.rt_quantize_rgb8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     _lib = lib

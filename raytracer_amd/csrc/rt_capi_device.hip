@@ -555,6 +555,118 @@ int buildTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std::vec
 	return levels;
 }
 
+// The same tree as quad nodes for the packet walks (layout in rt_kernels.h, reasons in rt_kernels.hip "Quad nodes"): the node that
+// stands for binary node n lists, for each child of n, that child's two children with their boxes -- or the child itself with its own
+// box where it is a leaf, or where it roots a sub-tree of the other regime (n a reference node, the child the conservative tree under
+// a fat leaf: the reference's exact verdict on the leaf's box must be kept).  A quad takes two 64 B slots of a treelet; the treelets
+// are cut as above (breadth first, a quad joins only if the triangles of its embeddable leaves fit as well).  Returns the number of
+// treelet levels, `quadDepth` = quads on the longest root-to-leaf path.
+int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std::vector<rt_bvh_node>& out, bool& externalRuns, int& quadDepth) {
+	out.clear();
+	externalRuns = false;
+	quadDepth = 0;
+	if (A.root < 0) return 0;
+	struct Entry { float box[6]; int32_t ref; };   // ref >= 0: binary node whose quad this entry leads to; < 0: ~index into A.leaves
+	auto entriesOf = [&](int32_t n, Entry* e) -> int {
+		const AugTree::Node& b = A.nodes[(size_t)n];
+		int count = 0;
+		for (int k = 0; k < 2; k++) {
+			const int32_t c = b.child[k];
+			static const uint32_t collapse = envU32("RT_QUAD_COLLAPSE", 3);   // diagnostic: bit 0 reference nodes, bit 1 sub-tree nodes
+			if (c >= 0 && A.nodes[(size_t)c].cons == b.cons && (collapse & (b.cons ? 2u : 1u))) {   // same regime: the child's own box is skipped
+				const AugTree::Node& m = A.nodes[(size_t)c];
+				for (int j = 0; j < 2; j++) { memcpy(e[count].box, m.box[j], sizeof e[count].box); e[count].ref = m.child[j]; count++; }
+			} else { memcpy(e[count].box, b.box[k], sizeof e[count].box); e[count].ref = c; count++; }
+		}
+		return count;
+	};
+	struct Root { int32_t node; int level; int depth; };
+	std::vector<Root> roots{ { A.root, 0, 1 } };
+	int levels = 0;
+	struct Member { int32_t node; int depth; Entry e[4]; int n; bool embedLeaf[4]; int32_t childSlot[4]; };
+	std::vector<Member> member;
+	out.reserve((A.nodes.size() / 2 + 64) * RT_TREELET_SLOTS);
+	auto embeddable = [&](int32_t c) -> uint32_t {
+		const AugTree::Leaf& L = A.leaves[(size_t)~c];
+		if (L.sub) return L.count;
+		return (embed && L.count > 0 && L.count <= RT_TREELET_EMBED_MAX && L.first < RT_TREELET_EMBED) ? L.count : 0u;
+	};
+	for (size_t t = 0; t < roots.size(); t++) {
+		out.resize((t + 1) * RT_TREELET_SLOTS, rt_bvh_node{});
+		const int level = roots[t].level;
+		levels = std::max(levels, level + 1);
+		member.clear();
+		uint32_t used = 0;
+		auto join = [&](int32_t node, int depth, bool must) {
+			Member m{};
+			m.node = node; m.depth = depth;
+			m.n = entriesOf(node, m.e);
+			uint32_t tris[4] = { 0, 0, 0, 0 }, all = 0;
+			for (int i = 0; i < m.n; i++) if (m.e[i].ref < 0) { tris[i] = embeddable(m.e[i].ref); all += tris[i]; }
+			if (!must && used + 2 + all > RT_TREELET_SLOTS) return false;
+			used += 2;
+			for (int i = 0; i < m.n; i++) {
+				m.childSlot[i] = -1;
+				m.embedLeaf[i] = tris[i] && used + tris[i] <= RT_TREELET_SLOTS;   // (the root joins whatever it brings; its runs are embedded while they fit)
+				if (m.embedLeaf[i]) used += tris[i];
+			}
+			quadDepth = std::max(quadDepth, depth);
+			member.push_back(m);
+			return true;
+		};
+		join(roots[t].node, roots[t].depth, true);
+		for (size_t i = 0; i < member.size(); i++)
+			for (int k = 0; k < member[i].n; k++) {
+				const int32_t ref = member[i].e[k].ref;
+				const int depth = member[i].depth + 1;
+				if (ref >= 0 && join(ref, depth, false)) member[i].childSlot[k] = 2 * ((int32_t)member.size() - 1);
+			}
+		uint32_t triSlot = 2u * (uint32_t)member.size();
+		for (size_t i = 0; i < member.size(); i++) {
+			const Member& m = member[i];
+			float* rec = reinterpret_cast<float*>(&out[t * RT_TREELET_SLOTS + 2 * i]);   // 32 floats: 4 boxes, 4 children, 4 aux words
+			int32_t* child = reinterpret_cast<int32_t*>(rec + 24);
+			uint32_t* aux = reinterpret_cast<uint32_t*>(rec + 28);
+			for (int k = 0; k < 4; k++) {
+				if (k >= m.n) {   // no such entry: a box nothing passes
+					for (int a = 0; a < 3; a++) { rec[6 * k + 2 * a] = 3.0e38f; rec[6 * k + 2 * a + 1] = -3.0e38f; }
+					child[k] = RT_QUAD_EMPTY; aux[k] = 0;
+					continue;
+				}
+				memcpy(rec + 6 * k, m.e[k].box, 6 * sizeof(float));
+				const int32_t c = m.e[k].ref;
+				if (c < 0) {
+					const AugTree::Leaf& L = A.leaves[(size_t)~c];
+					child[k] = L.sub ? -1 : L.ref;
+					if (m.embedLeaf[k]) {
+						aux[k] = L.count << 26 | RT_TREELET_EMBED | (uint32_t)level << 4 | triSlot;
+						for (uint32_t j = 0; j < L.count; j++, triSlot++) {
+							const uint32_t index = L.sub ? A.subTris[L.first + j] : L.first + j;
+							rt_tri tri = s->tris[index];
+							tri.mesh = (int32_t)index;                                                             // -> T.best
+							tri.uv = (int32_t)(L.sub ? A.subKeys[L.first + j] : (uint32_t)~L.ref + j + 1u);      // -> tie-break key
+							memcpy(&out[t * RT_TREELET_SLOTS + triSlot], &tri, sizeof tri);
+						}
+					} else {
+						if (L.sub) { rt::set_error("internal: a sub-leaf did not fit its treelet"); return -1; }
+						aux[k] = externalAux(TriRun{ L.first, L.count }, L.ref);
+						externalRuns |= aux[k] != RT_TREELET_NO_RUN;
+					}
+				} else {
+					const uint32_t flag = A.nodes[(size_t)c].cons ? RT_TREELET_CONS : 0u;
+					if (m.childSlot[k] >= 0) { child[k] = (int32_t)((uint32_t)(t * RT_TREELET_SLOTS + (size_t)m.childSlot[k]) | flag); aux[k] = 0; }
+					else {   // roots another treelet, one level further down (aux = what the walk adds to the level)
+						child[k] = (int32_t)((uint32_t)(roots.size() * RT_TREELET_SLOTS) | flag);
+						roots.push_back({ c, level + 1, m.depth + 1 });
+						aux[k] = 1;
+					}
+				}
+			}
+		}
+	}
+	return levels;
+}
+
 // Where a call's rays come from and where first-level results go.
 struct Source {
 	bool camera = false;
@@ -573,7 +685,7 @@ struct Run {
 	// Which traversal form a level uses.  Level 0 of a frame (and its shadow rays) is coherent by construction: 64
 	// consecutive queue slots are an 8x8 pixel block.  Deeper levels and caller-supplied rays are walked per lane.
 	int packetLevels = (int)envU32("RT_PACKET_LEVELS", 1);
-	bool coherent(int level) const { return src.camera && level < packetLevels; }
+	bool coherent(int level) const { static const bool dbg = getenv("RT_DBG_PACKET_BATCH") != nullptr; return (src.camera || dbg) && level < packetLevels; }
 
 	int syncCounters() {
 		if (int rcL = launchesOk()) return rcL;
@@ -967,7 +1079,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 		const double tA0 = now();
 		buildAugTree(s, getenv("RT_NO_SPLIT") == nullptr, aug);
 		const double tA1 = now();
-		if (aug.depth > RT_PACKET_STACK_DEPTH) buildAugTree(s, false, aug);   // (a leaf of > 4 * 2^20 triangles)
+		if (aug.depth > RT_STACK_DEPTH) buildAugTree(s, false, aug);   // (a leaf of > 4 * 2^20 triangles)
 		int levels = buildTreelets(s, aug, getenv("RT_NO_EMBED") == nullptr, treelets, externalRuns);
 		if (levels > RT_TREELET_MAX_LEVELS) { buildAugTree(s, false, aug); levels = buildTreelets(s, aug, false, treelets, externalRuns); }
 		if (levels < 0) return fail(RT_EINVAL);
@@ -978,6 +1090,24 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 		const rt_bvh_node* tl = nullptr;
 		if ((rc = sc->upload(treelets.data(), (int64_t)treelets.size(), &tl))) return fail(rc);
 		D.treelets = reinterpret_cast<const float4*>(tl);
+		{	// the packet walks' form of the same tree
+			std::vector<rt_bvh_node> quads;
+			bool quadRuns = false;
+			int quadDepth = 0;
+			const bool embedQ = getenv("RT_NO_EMBED") == nullptr;
+			int qlevels = buildQuadTreelets(s, aug, embedQ, quads, quadRuns, quadDepth);
+			if (qlevels > RT_TREELET_MAX_LEVELS) qlevels = buildQuadTreelets(s, aug, false, quads, quadRuns, quadDepth);
+			if (qlevels < 0) return fail(RT_EINVAL);
+			if (qlevels > RT_TREELET_MAX_LEVELS || quads.size() / RT_TREELET_SLOTS >= RT_TREELET_CONS / RT_TREELET_SLOTS || 3 * quadDepth + 1 > RT_PACKET_STACK_DEPTH) {
+				rt::set_error("BVH too deep or too large for the quad-node layout"); return fail(RT_ELIMIT);
+			}
+			if (timing) fprintf(stderr, "[upload] quads: %zu treelets, %d levels, depth %d\n", quads.size() / RT_TREELET_SLOTS, qlevels, quadDepth);
+			D.quad_levels = qlevels;
+			if (quadRuns) D.treelet_staging = 1;
+			const rt_bvh_node* ql = nullptr;
+			if ((rc = sc->upload(quads.data(), (int64_t)quads.size(), &ql))) return fail(rc);
+			D.quads = reinterpret_cast<const float4*>(ql);
+		}
 		D.treelet_root = s->root_child < 0 ? s->root_child : 0;
 		D.treelet_root_aux = (s->root_child < 0 && s->root_count > 0) ? externalAux(leafRun(s, s->root_child), s->root_child) : RT_TREELET_NO_RUN;
 		if (D.treelet_root_aux != RT_TREELET_NO_RUN) D.treelet_staging = 1;

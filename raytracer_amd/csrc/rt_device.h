@@ -158,6 +158,8 @@ struct DevScene {
 	const int32_t* mesh_order;         // their leaves: offsets into a mesh's triangles
 	const int32_t* mesh_root;          // per mesh: root node, or -1 = scan the triangles
 	const float4* treelets;            // the same tree cut into 1 KB treelets of up to 15 nodes (rt_kernels.h), device-only
+	const float4* quads;               // ... and once more as quad nodes (two slots each) for the packet walks (rt_kernels.h), device-only
+	int32_t quad_levels;               // treelets on the longest root-to-leaf path of that form (sizes the packet kernels' LDS)
 	int32_t treelet_root;              // 0 (slot 0 of treelet 0) or, for a one-leaf tree, the leaf reference
 	uint32_t treelet_root_aux;
 	int32_t treelet_levels;            // treelets on the longest root-to-leaf path (sizes the packet kernels' LDS)

@@ -53,7 +53,12 @@
 #define RT_TREELET_EMBED_MAX 8u           /* longest run that is embedded; longer all-triangle leaves get a sub-tree */
 #define RT_TREELET_SUBLEAF_MAX 4u         /* triangles per leaf of such a sub-tree */
 #define RT_TREELET_CONS (1u << 29)        /* flag on a child reference: the node belongs to a sub-tree, its box tests are conservative */
-#define RT_PACKET_STACK_DEPTH RT_STACK_DEPTH   /* wave stack entries */
+// Quad nodes (the packet walks' form of the tree, DevScene::quads): 128 B = two consecutive slots (the first one even) of such a
+// treelet: float box[4][6], int32 child[4], uint32 aux[4] -- child and aux as above (aux of an inner entry: 1 if it roots another
+// treelet, else 0), RT_QUAD_EMPTY for an entry that does not exist
+// (its box is inverted: nothing passes it).  RT_TREELET_CONS on the reference to a quad: its four boxes are conservative.
+#define RT_QUAD_EMPTY 0x7fffffff
+#define RT_PACKET_STACK_DEPTH 48   /* wave stack entries: a step of the quad walk leaves up to three behind, the tree is at most 15 quads deep */
 #define RT_PACKET_STACK_BYTES (RT_PACKET_STACK_DEPTH * 32)   /* 32 B per entry: the two-ray shadow walk carries two lane masks */
 // LDS of a packet kernel's workgroup: the root treelet once (every packet starts there; fetched when the workgroup
 // starts), then per wave one 1 KB buffer per deeper treelet level, one more when the scene has external runs to stage,

@@ -353,8 +353,13 @@ __device__ __forceinline__ void travRound(const DevScene& S, int32_t (*stack)[kB
 		int k0 = boxClassify(N.b0, T.e, T.inv, T.special, tlimit, t0);
 		int k1 = boxClassify(N.b1, T.e, T.inv, T.special, tlimit, t1);
 		if (k0 == 2 || k1 == 2) {   // too close to call with the multiply: a visit in a conservative sub-tree, else the reference's own arithmetic decides
-			if (k0 == 2) { if (cons) k0 = 1; else { const float t = boxIntersect(N.b0, T.e, T.d, false); k0 = !(t < 0 || t > tlimit); } }
-			if (k1 == 2) { if (cons) k1 = 1; else { const float t = boxIntersect(N.b1, T.e, T.d, false); k1 = !(t < 0 || t > tlimit); } }
+			// Nearest-hit walk: a box whose entry is within the margin of the best hit so far is visited whatever the exact comparison says.
+			// The reference prunes a box against the hits it found EARLIER in its own left-to-right order; this walk goes near child first,
+			// so its best hit may be one the reference finds later -- typically the other triangle of an edge the ray hits exactly, with
+			// the same t bit for bit -- and a box entry an ulp beyond that t (slab and triangle arithmetic round differently) would hide
+			// the triangle the reference found first.  Visiting costs a leaf test; the tie is then settled by the keys.
+			if (k0 == 2) { if (cons) k0 = 1; else { const float t = boxIntersect(N.b0, T.e, T.d, false); k0 = !(t < 0 || (ANYHIT && t > tlimit)); } }
+			if (k1 == 2) { if (cons) k1 = 1; else { const float t = boxIntersect(N.b1, T.e, T.d, false); k1 = !(t < 0 || (ANYHIT && t > tlimit)); } }
 		}
 		int take = -1;   // the child to continue with
 		if (k0 && k1) {
@@ -501,13 +506,13 @@ extern __shared__ float4 packetLdsRaw[];
 // call it once, at the top of the kernel, from every thread.
 __device__ __forceinline__ PacketLds packetLdsInit(const DevScene& S, bool withCold = false) {
 	PacketLds L;
-	const uint32_t perWave = (RT_PACKET_WAVE_LDS_BYTES(S.treelet_levels, S.treelet_staging) + (withCold ? RT_PACKET_COLD_BYTES : 0)) / 16;
+	const uint32_t perWave = (RT_PACKET_WAVE_LDS_BYTES(S.quad_levels, S.treelet_staging) + (withCold ? RT_PACKET_COLD_BYTES : 0)) / 16;
 	L.root = packetLdsRaw;
 	L.treelet = packetLdsRaw + 64 + (threadIdx.x >> 6) * perWave;
-	L.staging = S.treelet_levels > 1 ? (uint32_t)S.treelet_levels - 1u : 0u;
+	L.staging = S.quad_levels > 1 ? (uint32_t)S.quad_levels - 1u : 0u;
 	L.stack = reinterpret_cast<uint32_t (*)[8]>(L.treelet + (L.staging + (S.treelet_staging ? 1u : 0u)) * 64u);
 	L.cold = reinterpret_cast<float*>(L.stack + RT_PACKET_STACK_DEPTH) + (threadIdx.x & 63u);
-	if (threadIdx.x < 64 && S.treelet_root >= 0) L.root[threadIdx.x] = S.treelets[threadIdx.x];
+	if (threadIdx.x < 64 && S.treelet_root >= 0) L.root[threadIdx.x] = S.quads[threadIdx.x];
 	__syncthreads();
 	return L;
 }
@@ -557,6 +562,62 @@ __device__ __forceinline__ void packetTri(const DevScene& S, Trav& T, bool inSub
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Quad nodes.  The packet walks read the tree in a second form (DevScene::quads, built at upload beside the binary treelets the
+// per-lane walk keeps): a node holds the boxes of up to FOUR children -- the grandchildren of the binary node it stands for, or a
+// child itself where that is a leaf or roots a sub-tree of another regime (exact reference boxes above, conservative ones below a fat
+// leaf: a box is only skipped between boxes of one regime).  A step of the packet walk costs ~100 instructions before it has looked
+// at a box (node fetch, ballots, masks, stack, branches) and the kernels are bound by instruction issue: one step for two levels
+// pays that once, and the two child boxes in between are not tested at all.  Skipping a box is exact: the slab arithmetic is
+// monotone in the bounds, a box that contains another is entered no later and left no earlier in floating point as well, and the
+// reference's boxes nest exactly (min / max over subsets of the same primitives), so a ray that passes the inner box with the
+// reference's arithmetic would have passed every box around it.  Layout (rt_kernels.h): 128 B = two 64 B slots of a 1 KB treelet.
+// ---------------------------------------------------------------------------------------------------------
+struct QuadStep {
+	int32_t c[4];               // child references (wave-uniform); RT_QUAD_EMPTY = no such entry
+	uint32_t inf[4];            // what travels with each: treelet level (inner) or aux word (leaf)
+	unsigned long long m[4];    // lanes whose ray passed the entry's box
+};
+// Classifies the four boxes of the quad at `q` for this lane's ray.  KEYS: also the visiting keys of the nearest-hit walk -- entry
+// distance of the wave's first ray in the node (any order is correct; near first prunes more), index in the low two bits.
+template <bool KEYS>
+__device__ __forceinline__ void quadClassify(const float4* q, const Trav& T, f3 dExact, float tlimit, bool inSub, bool cons, uint32_t info, uint32_t firstLane, QuadStep& Q, uint32_t* keys) {
+	const float4 q6 = q[6], q7 = q[7];
+	Q.c[0] = __builtin_amdgcn_readfirstlane(__float_as_int(q6.x)); Q.c[1] = __builtin_amdgcn_readfirstlane(__float_as_int(q6.y));
+	Q.c[2] = __builtin_amdgcn_readfirstlane(__float_as_int(q6.z)); Q.c[3] = __builtin_amdgcn_readfirstlane(__float_as_int(q6.w));
+	const uint32_t x[4] = { (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.x)), (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.y)),
+	                        (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.z)), (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.w)) };
+	const bool live = inSub && !T.special;
+	const bool odd = inSub && T.special;   // 1/d not finite: every box goes to the exact test
+#pragma unroll
+	for (int pair = 0; pair < 2; pair++) {   // two boxes at a time: three 16 B words hold a pair
+		const float4 a = q[3 * pair], b = q[3 * pair + 1], c = q[3 * pair + 2];
+		const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
+		const float b1[6] = { b.z, b.w, c.x, c.y, c.z, c.w };
+		float t0, t1;
+		bool h0, h1, a0, a1;
+		boxClassifyFlat(b0, T.e, T.inv, tlimit, t0, h0, a0);
+		boxClassifyFlat(b1, T.e, T.inv, tlimit, t1, h1, a1);
+		const bool v0 = Q.c[2 * pair] != RT_QUAD_EMPTY, v1 = Q.c[2 * pair + 1] != RT_QUAD_EMPTY;   // (wave-uniform; applied to the lane masks below)
+		h0 = h0 && live; h1 = h1 && live;
+		a0 = (a0 && inSub) || odd; a1 = (a1 && inSub) || odd;
+		if (cons) { h0 = h0 || a0; h1 = h1 || a1; }   // too close to call = visit
+		else if (__ballot(a0 || a1) != 0) {   // too close to call somewhere in the wave (rare): the reference's own arithmetic decides
+			// KEYS = the nearest-hit walk, whose limit is the best hit so far: there a box this close to the limit is visited (see travRound)
+			if (a0 && v0) { const float t = boxIntersect(b0, T.e, dExact, false); h0 = !(t < 0 || (!KEYS && t > tlimit)); }
+			if (a1 && v1) { const float t = boxIntersect(b1, T.e, dExact, false); h1 = !(t < 0 || (!KEYS && t > tlimit)); }
+		}
+		Q.m[2 * pair] = v0 ? __ballot(h0) : 0ull; Q.m[2 * pair + 1] = v1 ? __ballot(h1) : 0ull;
+		if (KEYS) {
+			const uint32_t k0 = __float_as_uint(fmaxf(t0, 0.0f)), k1 = __float_as_uint(fmaxf(t1, 0.0f));
+			keys[2 * pair] = Q.m[2 * pair] ? (((uint32_t)__builtin_amdgcn_readlane((int)k0, (int)firstLane) & ~3u) | (uint32_t)(2 * pair)) : 0xffffffffu;
+			keys[2 * pair + 1] = Q.m[2 * pair + 1] ? (((uint32_t)__builtin_amdgcn_readlane((int)k1, (int)firstLane) & ~3u) | (uint32_t)(2 * pair + 1)) : 0xffffffffu;
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < 4; i++) Q.inf[i] = Q.c[i] < 0 ? x[i] : info + x[i];   // inner entry: aux = 1 if it roots another treelet (one level further down)
+}
+
 // `alive`: the lane holds a query.  T must come from travInit (T.cur == kEmpty: the lane's ray missed the root box).
 template <bool ANYHIT, bool CSG, bool COUNT>
 __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLds& L, Trav& T, bool alive, Tracer* trp = nullptr) {
@@ -584,50 +645,37 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			const int32_t nidx = (int32_t)((uint32_t)node & (RT_TREELET_CONS - 1u));
 			float4* buf = L.level(info);
 			if ((nidx & (RT_TREELET_SLOTS - 1)) == 0 && nidx != 0) {   // the root of a deeper treelet: stage it
-				buf[lane] = S.treelets[(size_t)nidx * 4 + lane];
+				buf[lane] = S.quads[(size_t)nidx * 4 + lane];
 				__builtin_amdgcn_wave_barrier();
 				TR(4, nidx >> 4);
 			}
-			const float4* q = buf + (nidx & (RT_TREELET_SLOTS - 1)) * 4;
-			const float4 a = q[0], b = q[1], c = q[2], d = q[3];
-			const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
-			const float b1[6] = { b.z, b.w, c.x, c.y, c.z, c.w };
-			// the references are the same in every lane: keep them in scalar registers
-			const int32_t c0 = __builtin_amdgcn_readfirstlane(__float_as_int(d.x)), c1 = __builtin_amdgcn_readfirstlane(__float_as_int(d.y));
-			const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(d.z)), x1 = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(d.w));
 			TR(12, 0);
 			const float tlimit = ANYHIT ? 1.0f : T.tmin;
-			float t0, t1;
-			bool h0, h1, a0, a1;
-			boxClassifyFlat(b0, T.e, T.inv, tlimit, t0, h0, a0);
-			boxClassifyFlat(b1, T.e, T.inv, tlimit, t1, h1, a1);
-			h0 = h0 && inSub && !T.special; h1 = h1 && inSub && !T.special;
-			a0 = (a0 || T.special) && inSub; a1 = (a1 || T.special) && inSub;
+			const unsigned long long mIn = __ballot(inSub);
+			const uint32_t firstLane = (uint32_t)__ffsll((long long)mIn) - 1u;
+			QuadStep Q;
+			uint32_t key[4] = { 0, 1, 2, 3 };
+			quadClassify<!ANYHIT>(buf + (nidx & (RT_TREELET_SLOTS - 1)) * 4, T, T.d, tlimit, inSub, cons, info, firstLane, Q, key);
 			if (COUNT || RT_PROF) T.cntNodes += inSub ? 1u : 0u;
 			if (COUNT) T.cntSteps++;
-			if (cons) { h0 = h0 || a0; h1 = h1 || a1; }   // too close to call = visit
-			else if (__ballot(a0 || a1) != 0) {   // too close to call somewhere in the wave (rare): the reference's own arithmetic decides
-				if (a0) { const float t = boxIntersect(b0, T.e, T.d, false); h0 = !(t < 0 || t > tlimit); }
-				if (a1) { const float t = boxIntersect(b1, T.e, T.d, false); h1 = !(t < 0 || t > tlimit); }
-			}
-			const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
-			TR(5, __popcll(m0 | m1));
-			// what travels with a child: its treelet level (one more when it roots another treelet) or its leaf aux word
-			const uint32_t i0 = c0 < 0 ? x0 : info + (((((uint32_t)c0 & (RT_TREELET_CONS - 1u)) ^ (uint32_t)nidx) >> 4) != 0);
-			const uint32_t i1 = c1 < 0 ? x1 : info + (((((uint32_t)c1 & (RT_TREELET_CONS - 1u)) ^ (uint32_t)nidx) >> 4) != 0);
-			if (m0 != 0 && m1 != 0) {
-				// visit first the child most rays reach first (any order is correct; ties go to the reference's order by key)
-				const bool swap = 2 * __popcll(__ballot(h0 && h1 && t1 < t0)) > __popcll(m0 & m1);
-				const unsigned long long mFar = swap ? m0 : m1;
-				if (sp < RT_PACKET_STACK_DEPTH) {
-					*reinterpret_cast<uint4*>(L.stack[sp]) = make_uint4((uint32_t)(swap ? c0 : c1), (uint32_t)mFar, (uint32_t)(mFar >> 32), swap ? i0 : i1);
-					sp++;
-				}
-				node = swap ? c1 : c0; info = swap ? i1 : i0;
-				inSub = swap ? h1 : h0;
-				popNext = false;
-			} else if (m0 != 0) { node = c0; info = i0; inSub = h0; popNext = false; }
-			else if (m1 != 0) { node = c1; info = i1; inSub = h1; popNext = false; }
+			TR(5, __popcll(Q.m[0] | Q.m[1] | Q.m[2] | Q.m[3]));
+			// The entry to go on with: the nearest one for the wave's first ray (nearest-hit walk), the first one any ray passed (shadow
+			// rays: any order is correct).  The other entries that some ray passed wait on the stack.  Written out per case: the entry's
+			// words are in scalar registers, and picking them by a run-time index costs more instructions than the step's box tests.
+#define RT_Q_PUSH(i) do { if (Q.m[i] != 0 && sp < RT_PACKET_STACK_DEPTH) { *reinterpret_cast<uint4*>(L.stack[sp]) = make_uint4((uint32_t)Q.c[i], (uint32_t)Q.m[i], (uint32_t)(Q.m[i] >> 32), Q.inf[i]); sp++; } } while (0)
+#define RT_Q_TAKE(i) do { node = Q.c[i]; info = Q.inf[i]; inSub = ((Q.m[i] >> lane) & 1ull) != 0; popNext = false; } while (0)
+			uint32_t first;
+			if (!ANYHIT) {
+				const uint32_t k01 = key[0] < key[1] ? key[0] : key[1], k23 = key[2] < key[3] ? key[2] : key[3];
+				const uint32_t kmin = k01 < k23 ? k01 : k23;
+				first = kmin == 0xffffffffu ? 4u : kmin & 3u;
+			} else first = Q.m[0] ? 0u : Q.m[1] ? 1u : Q.m[2] ? 2u : Q.m[3] ? 3u : 4u;
+			if (first == 0u) { RT_Q_PUSH(3); RT_Q_PUSH(2); RT_Q_PUSH(1); RT_Q_TAKE(0); }
+			else if (first == 1u) { RT_Q_PUSH(3); RT_Q_PUSH(2); if (!ANYHIT) RT_Q_PUSH(0); RT_Q_TAKE(1); }
+			else if (first == 2u) { RT_Q_PUSH(3); if (!ANYHIT) { RT_Q_PUSH(1); RT_Q_PUSH(0); } RT_Q_TAKE(2); }
+			else if (first == 3u) { if (!ANYHIT) { RT_Q_PUSH(2); RT_Q_PUSH(1); RT_Q_PUSH(0); } RT_Q_TAKE(3); }
+#undef RT_Q_PUSH
+#undef RT_Q_TAKE
 			TR(6, sp);
 		} else if (info != RT_TREELET_NO_RUN) {   // leaf made of consecutive triangles: no leaf_prims indirection
 			const bool longRun = (info >> 26) == 0u;   // external run in its long form: info = count, first triangle = first leaf entry
@@ -703,50 +751,57 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 			const int32_t nidx = (int32_t)((uint32_t)node & (RT_TREELET_CONS - 1u));
 			float4* buf = L.level(info);
 			if ((nidx & (RT_TREELET_SLOTS - 1)) == 0 && nidx != 0) {
-				buf[lane] = S.treelets[(size_t)nidx * 4 + lane];
+				buf[lane] = S.quads[(size_t)nidx * 4 + lane];
 				__builtin_amdgcn_wave_barrier();
 			}
 			const float4* q = buf + (nidx & (RT_TREELET_SLOTS - 1)) * 4;
-			const float4 a = q[0], b = q[1], c = q[2], d = q[3];
-			const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
-			const float b1[6] = { b.z, b.w, c.x, c.y, c.z, c.w };
-			const int32_t c0 = __builtin_amdgcn_readfirstlane(__float_as_int(d.x)), c1 = __builtin_amdgcn_readfirstlane(__float_as_int(d.y));
-			const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(d.z)), x1 = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(d.w));
-			float t;
-			bool h0A, h1A, h0B, h1B, a0A, a1A, a0B, a1B;
-			boxClassifyFlat(b0, A.e, A.inv, 1.0f, t, h0A, a0A);
-			boxClassifyFlat(b1, A.e, A.inv, 1.0f, t, h1A, a1A);
-#if RT_SCHED_SPLIT
-			__builtin_amdgcn_sched_barrier(0);
-#endif
-			boxClassifyFlat(b0, A.e, B.inv, 1.0f, t, h0B, a0B);
-			boxClassifyFlat(b1, A.e, B.inv, 1.0f, t, h1B, a1B);
-			h0A = h0A && inA && !A.special; h1A = h1A && inA && !A.special;
-			a0A = (a0A || A.special) && inA; a1A = (a1A || A.special) && inA;
-			h0B = h0B && inB && !B.special; h1B = h1B && inB && !B.special;
-			a0B = (a0B || B.special) && inB; a1B = (a1B || B.special) && inB;
+			const float4 q6 = q[6], q7 = q[7];
+			const int32_t c[4] = { __builtin_amdgcn_readfirstlane(__float_as_int(q6.x)), __builtin_amdgcn_readfirstlane(__float_as_int(q6.y)),
+			                       __builtin_amdgcn_readfirstlane(__float_as_int(q6.z)), __builtin_amdgcn_readfirstlane(__float_as_int(q6.w)) };
+			const uint32_t x[4] = { (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.x)), (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.y)),
+			                        (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.z)), (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.w)) };
+			unsigned long long mA[4], mB[4];
 			if (COUNT) { A.cntNodes += inA ? 1u : 0u; B.cntNodes += inB ? 1u : 0u; A.cntSteps++; }
-			if (cons) { h0A = h0A || a0A; h1A = h1A || a1A; h0B = h0B || a0B; h1B = h1B || a1B; }
-			else if (__ballot(a0A || a1A || a0B || a1B) != 0) {   // too close to call somewhere (rare): the reference's own arithmetic decides
-				A.d = coldLd3(L.cold, COLD_DA); B.d = coldLd3(L.cold, COLD_DB);
-				if (a0A) { const float tt = boxIntersect(b0, A.e, A.d, false); h0A = !(tt < 0 || tt > 1.0f); }
-				if (a1A) { const float tt = boxIntersect(b1, A.e, A.d, false); h1A = !(tt < 0 || tt > 1.0f); }
-				if (a0B) { const float tt = boxIntersect(b0, A.e, B.d, false); h0B = !(tt < 0 || tt > 1.0f); }
-				if (a1B) { const float tt = boxIntersect(b1, A.e, B.d, false); h1B = !(tt < 0 || tt > 1.0f); }
-			}
-			const unsigned long long m0A = __ballot(h0A), m1A = __ballot(h1A), m0B = __ballot(h0B), m1B = __ballot(h1B);
-			const uint32_t i0 = c0 < 0 ? x0 : info + (((((uint32_t)c0 & (RT_TREELET_CONS - 1u)) ^ (uint32_t)nidx) >> 4) != 0);
-			const uint32_t i1 = c1 < 0 ? x1 : info + (((((uint32_t)c1 & (RT_TREELET_CONS - 1u)) ^ (uint32_t)nidx) >> 4) != 0);
-			const bool any0 = (m0A | m0B) != 0, any1 = (m1A | m1B) != 0;
-			if (any0 && any1) {
-				if (sp < RT_PACKET_STACK_DEPTH) {
-					stack[2 * sp] = make_uint4((uint32_t)c1, i1, 0u, 0u);
-					stack[2 * sp + 1] = make_uint4((uint32_t)m1A, (uint32_t)(m1A >> 32), (uint32_t)m1B, (uint32_t)(m1B >> 32));
-					sp++;
+			const bool liveA = inA && !A.special, liveB = inB && !B.special;
+			const bool oddA = inA && A.special, oddB = inB && B.special;
+#pragma unroll
+			for (int pair = 0; pair < 2; pair++) {
+				const float4 a = q[3 * pair], b = q[3 * pair + 1], cc = q[3 * pair + 2];
+				const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
+				const float b1[6] = { b.z, b.w, cc.x, cc.y, cc.z, cc.w };
+				const bool v0 = c[2 * pair] != RT_QUAD_EMPTY, v1 = c[2 * pair + 1] != RT_QUAD_EMPTY;   // (wave-uniform; applied to the lane masks)
+				float t;
+				bool h0A, h1A, h0B, h1B, a0A, a1A, a0B, a1B;
+				boxClassifyFlat(b0, A.e, A.inv, 1.0f, t, h0A, a0A);
+				boxClassifyFlat(b1, A.e, A.inv, 1.0f, t, h1A, a1A);
+				boxClassifyFlat(b0, A.e, B.inv, 1.0f, t, h0B, a0B);
+				boxClassifyFlat(b1, A.e, B.inv, 1.0f, t, h1B, a1B);
+				h0A = h0A && liveA; h1A = h1A && liveA; h0B = h0B && liveB; h1B = h1B && liveB;
+				a0A = (a0A && inA) || oddA; a1A = (a1A && inA) || oddA; a0B = (a0B && inB) || oddB; a1B = (a1B && inB) || oddB;
+				if (cons) { h0A = h0A || a0A; h1A = h1A || a1A; h0B = h0B || a0B; h1B = h1B || a1B; }
+				else if (__ballot(a0A || a1A || a0B || a1B) != 0) {   // too close to call somewhere (rare): the reference's own arithmetic decides
+					A.d = coldLd3(L.cold, COLD_DA); B.d = coldLd3(L.cold, COLD_DB);
+					if (a0A && v0) { const float tt = boxIntersect(b0, A.e, A.d, false); h0A = !(tt < 0 || tt > 1.0f); }
+					if (a1A && v1) { const float tt = boxIntersect(b1, A.e, A.d, false); h1A = !(tt < 0 || tt > 1.0f); }
+					if (a0B && v0) { const float tt = boxIntersect(b0, A.e, B.d, false); h0B = !(tt < 0 || tt > 1.0f); }
+					if (a1B && v1) { const float tt = boxIntersect(b1, A.e, B.d, false); h1B = !(tt < 0 || tt > 1.0f); }
 				}
-				node = c0; info = i0; inA = h0A; inB = h0B; popNext = false;
-			} else if (any0) { node = c0; info = i0; inA = h0A; inB = h0B; popNext = false; }
-			else if (any1) { node = c1; info = i1; inA = h1A; inB = h1B; popNext = false; }
+				mA[2 * pair] = v0 ? __ballot(h0A) : 0ull; mA[2 * pair + 1] = v1 ? __ballot(h1A) : 0ull;
+				mB[2 * pair] = v0 ? __ballot(h0B) : 0ull; mB[2 * pair + 1] = v1 ? __ballot(h1B) : 0ull;
+			}
+			// the first entry any ray passed is walked next, the others wait on the stack (any order is correct for shadow rays); written
+			// out per case, see packetTraverse
+#define RT_Q_INF(i) (c[i] < 0 ? x[i] : info + x[i])
+#define RT_Q_PUSH(i) do { if ((mA[i] | mB[i]) != 0 && sp < RT_PACKET_STACK_DEPTH) { stack[2 * sp] = make_uint4((uint32_t)c[i], RT_Q_INF(i), 0u, 0u); \
+				stack[2 * sp + 1] = make_uint4((uint32_t)mA[i], (uint32_t)(mA[i] >> 32), (uint32_t)mB[i], (uint32_t)(mB[i] >> 32)); sp++; } } while (0)
+#define RT_Q_TAKE(i) do { const uint32_t inf_ = RT_Q_INF(i); node = c[i]; info = inf_; inA = ((mA[i] >> lane) & 1ull) != 0; inB = ((mB[i] >> lane) & 1ull) != 0; popNext = false; } while (0)
+			if ((mA[0] | mB[0]) != 0) { RT_Q_PUSH(3); RT_Q_PUSH(2); RT_Q_PUSH(1); RT_Q_TAKE(0); }
+			else if ((mA[1] | mB[1]) != 0) { RT_Q_PUSH(3); RT_Q_PUSH(2); RT_Q_TAKE(1); }
+			else if ((mA[2] | mB[2]) != 0) { RT_Q_PUSH(3); RT_Q_TAKE(2); }
+			else if ((mA[3] | mB[3]) != 0) { RT_Q_TAKE(3); }
+#undef RT_Q_INF
+#undef RT_Q_PUSH
+#undef RT_Q_TAKE
 		} else if (info != RT_TREELET_NO_RUN) {
 			const bool longRun = (info >> 26) == 0u;
 			const uint32_t count = longRun ? info : info >> 26;
@@ -1834,7 +1889,7 @@ template <class K> static int residentPerCU(K kernel, const char* name, size_t l
 		RT_LAUNCH_RAW(kernel, dim3(gridPersistent(n, std::min(maxBlocks, _perCU * computeUnits()))), dim3(kBlock), (size_t)(lds), stream, __VA_ARGS__); } } while (0)
 #define RT_LAUNCH_P(kernel, n, maxBlocks, stream, ...) RT_LAUNCH_PS(kernel, n, maxBlocks, 0, stream, __VA_ARGS__)
 #define RT_LAUNCH_S(kernel, n, lds, stream, ...) do { if ((n) > 0) RT_LAUNCH_RAW(kernel, dim3(gridFor(n)), dim3(kBlock), lds, stream, __VA_ARGS__); } while (0)
-static size_t packetLdsBytes(const DevScene& S) { return (size_t)RT_PACKET_LDS_BYTES(S.treelet_levels, S.treelet_staging); }
+static size_t packetLdsBytes(const DevScene& S) { return (size_t)RT_PACKET_LDS_BYTES(S.quad_levels, S.treelet_staging); }
 
 void rtk_generate(hipStream_t st, const rt_camera& cam, int W, int H, int aaX, int aaY, int tileRank, int tileRanks, uint32_t r0, uint32_t count, RtQueue rq) {
 	RT_LAUNCH(k_generate, count, st, cam, W, H, aaX, aaY, tileRank, tileRanks, r0, count, rq);
@@ -1908,6 +1963,7 @@ void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint3
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                       RtAccum A, uint32_t aaSq, RtCounters* ctr, bool countOnDevice, int maxBlocksPairs) {
 	const int cod = countOnDevice ? 1 : 0;   // packet kernels only: nsurf is a bound, the kernels read the count from ctr
+	if (getenv("RT_DBG_SHADOW_PERLANE")) coherent = false;
 	const unsigned long long items = (unsigned long long)nsurf * nLights;
 	const bool noPairs = getenv("RT_NO_LIGHT_PAIRS") != nullptr;   // (read per call: the tests switch it)
 	if (coherent && nLights >= 2 && !noPairs) {   // two lights per packet; an odd last one in a launch of its own (with its own cursor)

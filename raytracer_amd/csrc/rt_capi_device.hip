@@ -685,7 +685,9 @@ struct Run {
 	// Which traversal form a level uses.  Level 0 of a frame (and its shadow rays) is coherent by construction: 64
 	// consecutive queue slots are an 8x8 pixel block.  Deeper levels and caller-supplied rays are walked per lane.
 	int packetLevels = (int)envU32("RT_PACKET_LEVELS", 1);
-	bool coherent(int level) const { static const bool dbg = getenv("RT_DBG_PACKET_BATCH") != nullptr; return (src.camera || dbg) && level < packetLevels; }
+	// (RT_PACKET_BATCHES: caller-supplied rays go through the packet kernels too, 64 consecutive rays per packet -- what the tests use to
+	// compare the two walks on the same rays; read per call)
+	bool coherent(int level) const { return (src.camera || getenv("RT_PACKET_BATCHES") != nullptr) && level < packetLevels; }
 
 	int syncCounters() {
 		if (int rcL = launchesOk()) return rcL;
@@ -1084,7 +1086,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 		if (levels > RT_TREELET_MAX_LEVELS) { buildAugTree(s, false, aug); levels = buildTreelets(s, aug, false, treelets, externalRuns); }
 		if (levels < 0) return fail(RT_EINVAL);
 		if (levels > RT_TREELET_MAX_LEVELS || treelets.size() / RT_TREELET_SLOTS >= RT_TREELET_CONS / RT_TREELET_SLOTS) { rt::set_error("BVH too deep or too large for the treelet layout"); return fail(RT_ELIMIT); }
-		if (timing) fprintf(stderr, "[upload] arrays + mesh trees %.2f s, sub-trees %.2f s, treelets %.2f s\n", tA0 - tUp0, tA1 - tA0, now() - tA1);
+		if (timing) fprintf(stderr, "[upload] arrays + mesh trees %.2f s, sub-trees %.2f s, treelets %.2f s: %zu treelets, %d levels, tree depth %d\n", tA0 - tUp0, tA1 - tA0, now() - tA1, treelets.size() / RT_TREELET_SLOTS, levels, aug.depth);
 		D.treelet_levels = levels;
 		D.treelet_staging = externalRuns ? 1 : 0;
 		const rt_bvh_node* tl = nullptr;

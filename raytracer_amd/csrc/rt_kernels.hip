@@ -591,6 +591,12 @@ __device__ __forceinline__ void quadClassify(const float4* q, const Trav& T, f3 
 	const bool odd = inSub && T.special;   // 1/d not finite: every box goes to the exact test
 #pragma unroll
 	for (int pair = 0; pair < 2; pair++) {   // two boxes at a time: three 16 B words hold a pair
+		const bool v0 = Q.c[2 * pair] != RT_QUAD_EMPTY, v1 = Q.c[2 * pair + 1] != RT_QUAD_EMPTY;   // (wave-uniform; applied to the lane masks below)
+		if (pair == 1 && !v0) {   // a quad of two entries (entries fill from the front): nothing in the second pair
+			Q.m[2] = 0; Q.m[3] = 0;
+			if (KEYS) { keys[2] = 0xffffffffu; keys[3] = 0xffffffffu; }
+			continue;
+		}
 		const float4 a = q[3 * pair], b = q[3 * pair + 1], c = q[3 * pair + 2];
 		const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
 		const float b1[6] = { b.z, b.w, c.x, c.y, c.z, c.w };
@@ -598,7 +604,6 @@ __device__ __forceinline__ void quadClassify(const float4* q, const Trav& T, f3 
 		bool h0, h1, a0, a1;
 		boxClassifyFlat(b0, T.e, T.inv, tlimit, t0, h0, a0);
 		boxClassifyFlat(b1, T.e, T.inv, tlimit, t1, h1, a1);
-		const bool v0 = Q.c[2 * pair] != RT_QUAD_EMPTY, v1 = Q.c[2 * pair + 1] != RT_QUAD_EMPTY;   // (wave-uniform; applied to the lane masks below)
 		h0 = h0 && live; h1 = h1 && live;
 		a0 = (a0 && inSub) || odd; a1 = (a1 && inSub) || odd;
 		if (cons) { h0 = h0 || a0; h1 = h1 || a1; }   // too close to call = visit
@@ -766,10 +771,11 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 			const bool oddA = inA && A.special, oddB = inB && B.special;
 #pragma unroll
 			for (int pair = 0; pair < 2; pair++) {
+				const bool v0 = c[2 * pair] != RT_QUAD_EMPTY, v1 = c[2 * pair + 1] != RT_QUAD_EMPTY;   // (wave-uniform; applied to the lane masks)
+				if (pair == 1 && !v0) { mA[2] = mA[3] = mB[2] = mB[3] = 0; continue; }   // a quad of two entries: nothing in the second pair
 				const float4 a = q[3 * pair], b = q[3 * pair + 1], cc = q[3 * pair + 2];
 				const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
 				const float b1[6] = { b.z, b.w, cc.x, cc.y, cc.z, cc.w };
-				const bool v0 = c[2 * pair] != RT_QUAD_EMPTY, v1 = c[2 * pair + 1] != RT_QUAD_EMPTY;   // (wave-uniform; applied to the lane masks)
 				float t;
 				bool h0A, h1A, h0B, h1B, a0A, a1A, a0B, a1B;
 				boxClassifyFlat(b0, A.e, A.inv, 1.0f, t, h0A, a0A);
@@ -1963,7 +1969,6 @@ void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint3
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                       RtAccum A, uint32_t aaSq, RtCounters* ctr, bool countOnDevice, int maxBlocksPairs) {
 	const int cod = countOnDevice ? 1 : 0;   // packet kernels only: nsurf is a bound, the kernels read the count from ctr
-	if (getenv("RT_DBG_SHADOW_PERLANE")) coherent = false;
 	const unsigned long long items = (unsigned long long)nsurf * nLights;
 	const bool noPairs = getenv("RT_NO_LIGHT_PAIRS") != nullptr;   // (read per call: the tests switch it)
 	if (coherent && nLights >= 2 && !noPairs) {   // two lights per packet; an odd last one in a launch of its own (with its own cursor)

@@ -585,14 +585,14 @@ int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std:
 	int levels = 0;
 	struct Member { int32_t node; int depth; Entry e[4]; int n; bool embedLeaf[4]; int32_t childSlot[4]; };
 	std::vector<Member> member;
-	out.reserve((A.nodes.size() / 2 + 64) * RT_TREELET_SLOTS);
+	out.reserve((A.nodes.size() / 2 + 64) * RT_QUAD_SLOTS);
 	auto embeddable = [&](int32_t c) -> uint32_t {
 		const AugTree::Leaf& L = A.leaves[(size_t)~c];
 		if (L.sub) return L.count;
 		return (embed && L.count > 0 && L.count <= RT_TREELET_EMBED_MAX && L.first < RT_TREELET_EMBED) ? L.count : 0u;
 	};
 	for (size_t t = 0; t < roots.size(); t++) {
-		out.resize((t + 1) * RT_TREELET_SLOTS, rt_bvh_node{});
+		out.resize((t + 1) * RT_QUAD_SLOTS, rt_bvh_node{});
 		const int level = roots[t].level;
 		levels = std::max(levels, level + 1);
 		member.clear();
@@ -603,11 +603,11 @@ int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std:
 			m.n = entriesOf(node, m.e);
 			uint32_t tris[4] = { 0, 0, 0, 0 }, all = 0;
 			for (int i = 0; i < m.n; i++) if (m.e[i].ref < 0) { tris[i] = embeddable(m.e[i].ref); all += tris[i]; }
-			if (!must && used + 2 + all > RT_TREELET_SLOTS) return false;
+			if (!must && used + 2 + all > RT_QUAD_SLOTS) return false;
 			used += 2;
 			for (int i = 0; i < m.n; i++) {
 				m.childSlot[i] = -1;
-				m.embedLeaf[i] = tris[i] && used + tris[i] <= RT_TREELET_SLOTS;   // (the root joins whatever it brings; its runs are embedded while they fit)
+				m.embedLeaf[i] = tris[i] && used + tris[i] <= RT_QUAD_SLOTS;   // (the root joins whatever it brings; its runs are embedded while they fit)
 				if (m.embedLeaf[i]) used += tris[i];
 			}
 			quadDepth = std::max(quadDepth, depth);
@@ -624,7 +624,7 @@ int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std:
 		uint32_t triSlot = 2u * (uint32_t)member.size();
 		for (size_t i = 0; i < member.size(); i++) {
 			const Member& m = member[i];
-			float* rec = reinterpret_cast<float*>(&out[t * RT_TREELET_SLOTS + 2 * i]);   // 32 floats: 4 boxes, 4 children, 4 aux words
+			float* rec = reinterpret_cast<float*>(&out[t * RT_QUAD_SLOTS + 2 * i]);   // 32 floats: 4 boxes, 4 children, 4 aux words
 			int32_t* child = reinterpret_cast<int32_t*>(rec + 24);
 			uint32_t* aux = reinterpret_cast<uint32_t*>(rec + 28);
 			for (int k = 0; k < 4; k++) {
@@ -639,13 +639,13 @@ int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std:
 					const AugTree::Leaf& L = A.leaves[(size_t)~c];
 					child[k] = L.sub ? -1 : L.ref;
 					if (m.embedLeaf[k]) {
-						aux[k] = L.count << 26 | RT_TREELET_EMBED | (uint32_t)level << 4 | triSlot;
+						aux[k] = L.count << 26 | RT_TREELET_EMBED | (uint32_t)level << RT_QUAD_SLOT_BITS | triSlot;
 						for (uint32_t j = 0; j < L.count; j++, triSlot++) {
 							const uint32_t index = L.sub ? A.subTris[L.first + j] : L.first + j;
 							rt_tri tri = s->tris[index];
 							tri.mesh = (int32_t)index;                                                             // -> T.best
 							tri.uv = (int32_t)(L.sub ? A.subKeys[L.first + j] : (uint32_t)~L.ref + j + 1u);      // -> tie-break key
-							memcpy(&out[t * RT_TREELET_SLOTS + triSlot], &tri, sizeof tri);
+							memcpy(&out[t * RT_QUAD_SLOTS + triSlot], &tri, sizeof tri);
 						}
 					} else {
 						if (L.sub) { rt::set_error("internal: a sub-leaf did not fit its treelet"); return -1; }
@@ -654,9 +654,9 @@ int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std:
 					}
 				} else {
 					const uint32_t flag = A.nodes[(size_t)c].cons ? RT_TREELET_CONS : 0u;
-					if (m.childSlot[k] >= 0) { child[k] = (int32_t)((uint32_t)(t * RT_TREELET_SLOTS + (size_t)m.childSlot[k]) | flag); aux[k] = 0; }
+					if (m.childSlot[k] >= 0) { child[k] = (int32_t)((uint32_t)(t * RT_QUAD_SLOTS + (size_t)m.childSlot[k]) | flag); aux[k] = 0; }
 					else {   // roots another treelet, one level further down (aux = what the walk adds to the level)
-						child[k] = (int32_t)((uint32_t)(roots.size() * RT_TREELET_SLOTS) | flag);
+						child[k] = (int32_t)((uint32_t)(roots.size() * RT_QUAD_SLOTS) | flag);
 						roots.push_back({ c, level + 1, m.depth + 1 });
 						aux[k] = 1;
 					}
@@ -1100,10 +1100,10 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 			int qlevels = buildQuadTreelets(s, aug, embedQ, quads, quadRuns, quadDepth);
 			if (qlevels > RT_TREELET_MAX_LEVELS) qlevels = buildQuadTreelets(s, aug, false, quads, quadRuns, quadDepth);
 			if (qlevels < 0) return fail(RT_EINVAL);
-			if (qlevels > RT_TREELET_MAX_LEVELS || quads.size() / RT_TREELET_SLOTS >= RT_TREELET_CONS / RT_TREELET_SLOTS || 3 * quadDepth + 1 > RT_PACKET_STACK_DEPTH) {
+			if (qlevels > RT_TREELET_MAX_LEVELS || quads.size() / RT_QUAD_SLOTS >= RT_TREELET_CONS / RT_QUAD_SLOTS || 3 * quadDepth + 1 > RT_PACKET_STACK_DEPTH) {
 				rt::set_error("BVH too deep or too large for the quad-node layout"); return fail(RT_ELIMIT);
 			}
-			if (timing) fprintf(stderr, "[upload] quads: %zu treelets, %d levels, depth %d\n", quads.size() / RT_TREELET_SLOTS, qlevels, quadDepth);
+			if (timing) fprintf(stderr, "[upload] quads: %zu treelets, %d levels, depth %d\n", quads.size() / RT_QUAD_SLOTS, qlevels, quadDepth);
 			D.quad_levels = qlevels;
 			if (quadRuns) D.treelet_staging = 1;
 			const rt_bvh_node* ql = nullptr;

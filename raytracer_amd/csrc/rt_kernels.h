@@ -58,15 +58,21 @@
 // treelet, else 0), RT_QUAD_EMPTY for an entry that does not exist
 // (its box is inverted: nothing passes it).  RT_TREELET_CONS on the reference to a quad: its four boxes are conservative.
 #define RT_QUAD_EMPTY 0x7fffffff
+#ifndef RT_QUAD_SLOTS
+#define RT_QUAD_SLOTS 16                   /* 64 B slots per treelet of the quad form (1 KB: one 16 B-per-lane load of a wave).  32 was measured: the kernels alone take the same time -- the C2 tree keeps its 5 treelet levels -- and the larger LDS footprint costs the pipelined frame 12 % (C5: 10 %) */
+#endif
+#define RT_QUAD_SLOT_BITS (RT_QUAD_SLOTS == 32 ? 5 : 4)
+#define RT_QUAD_TREELET_BYTES (RT_QUAD_SLOTS * 64)
+/* aux of an embedded run in the quad form: count << 26 | RT_TREELET_EMBED | level << RT_QUAD_SLOT_BITS | slot */
 #define RT_PACKET_STACK_DEPTH 48   /* wave stack entries: a step of the quad walk leaves up to three behind, the tree is at most 15 quads deep */
 #define RT_PACKET_STACK_BYTES (RT_PACKET_STACK_DEPTH * 32)   /* 32 B per entry: the two-ray shadow walk carries two lane masks */
 // LDS of a packet kernel's workgroup: the root treelet once (every packet starts there; fetched when the workgroup
 // starts), then per wave one 1 KB buffer per deeper treelet level, one more when the scene has external runs to stage,
 // and the stack
-#define RT_PACKET_WAVE_LDS_BYTES(levels, staging) ((((levels) > 1 ? (levels) - 1 : 0) + ((staging) ? 1 : 0)) * 1024 + RT_PACKET_STACK_BYTES)
+#define RT_PACKET_WAVE_LDS_BYTES(levels, staging) ((((levels) > 1 ? (levels) - 1 : 0) + ((staging) ? 1 : 0)) * RT_QUAD_TREELET_BYTES + RT_PACKET_STACK_BYTES)
 #define RT_COLD_FLOATS 16                                    /* per lane: two directions, two lengths, two attenuation colours (14 used) */
 #define RT_PACKET_COLD_BYTES (RT_COLD_FLOATS * 64 * 4)       /* per wave, k_shadow_point_packet2 only, behind the stack */
-#define RT_PACKET_LDS_BYTES(levels, staging) (1024 + (RT_BLOCK / 64) * RT_PACKET_WAVE_LDS_BYTES(levels, staging))
+#define RT_PACKET_LDS_BYTES(levels, staging) (RT_QUAD_TREELET_BYTES + (RT_BLOCK / 64) * RT_PACKET_WAVE_LDS_BYTES(levels, staging))
 
 // SoA queue: component c of slot i lives at f[c * cap + i]
 struct RtQueue { float* f; uint32_t cap; };

@@ -493,7 +493,7 @@ struct PacketLds {
 	uint32_t (*stack)[8];       // [RT_PACKET_STACK_DEPTH] x 32 B: node, lane mask lo/hi, level (inner) or aux (leaf); the two-ray walk uses all 32 B
 	uint32_t staging;           // index of the staging buffer in treelet[]
 	float* cold;                // two-ray shadow walk only: [RT_COLD_FLOATS][64] per-lane state that only leaves touch (this lane's column)
-	__device__ __forceinline__ float4* level(uint32_t l) const { return l == 0 ? root : treelet + (l - 1u) * 64u; }
+	__device__ __forceinline__ float4* level(uint32_t l) const { return l == 0 ? root : treelet + (l - 1u) * (RT_QUAD_SLOTS * 4u); }
 };
 // Per-lane state of the two-ray shadow walk that only the leaves (and the rare exact box test) need -- the two directions, their
 // lengths, the two attenuation colours -- lives in LDS, one column per lane, and is loaded where it is used: 14 registers fewer are
@@ -508,11 +508,11 @@ __device__ __forceinline__ PacketLds packetLdsInit(const DevScene& S, bool withC
 	PacketLds L;
 	const uint32_t perWave = (RT_PACKET_WAVE_LDS_BYTES(S.quad_levels, S.treelet_staging) + (withCold ? RT_PACKET_COLD_BYTES : 0)) / 16;
 	L.root = packetLdsRaw;
-	L.treelet = packetLdsRaw + 64 + (threadIdx.x >> 6) * perWave;
+	L.treelet = packetLdsRaw + RT_QUAD_SLOTS * 4 + (threadIdx.x >> 6) * perWave;
 	L.staging = S.quad_levels > 1 ? (uint32_t)S.quad_levels - 1u : 0u;
-	L.stack = reinterpret_cast<uint32_t (*)[8]>(L.treelet + (L.staging + (S.treelet_staging ? 1u : 0u)) * 64u);
+	L.stack = reinterpret_cast<uint32_t (*)[8]>(L.treelet + (L.staging + (S.treelet_staging ? 1u : 0u)) * (RT_QUAD_SLOTS * 4u));
 	L.cold = reinterpret_cast<float*>(L.stack + RT_PACKET_STACK_DEPTH) + (threadIdx.x & 63u);
-	if (threadIdx.x < 64 && S.treelet_root >= 0) L.root[threadIdx.x] = S.quads[threadIdx.x];
+	if (threadIdx.x < RT_QUAD_SLOTS * 4 && S.treelet_root >= 0) L.root[threadIdx.x] = S.quads[threadIdx.x];
 	__syncthreads();
 	return L;
 }
@@ -649,8 +649,9 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			const bool cons = ((uint32_t)node & RT_TREELET_CONS) != 0u;   // a node of a sub-tree under a fat leaf: conservative box tests
 			const int32_t nidx = (int32_t)((uint32_t)node & (RT_TREELET_CONS - 1u));
 			float4* buf = L.level(info);
-			if ((nidx & (RT_TREELET_SLOTS - 1)) == 0 && nidx != 0) {   // the root of a deeper treelet: stage it
-				buf[lane] = S.quads[(size_t)nidx * 4 + lane];
+			if ((nidx & (RT_QUAD_SLOTS - 1)) == 0 && nidx != 0) {   // the root of a deeper treelet: stage it
+#pragma unroll
+				for (uint32_t k = 0; k < RT_QUAD_SLOTS * 4u; k += 64u) buf[k + lane] = S.quads[(size_t)nidx * 4 + k + lane];
 				__builtin_amdgcn_wave_barrier();
 				TR(4, nidx >> 4);
 			}
@@ -660,7 +661,7 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			const uint32_t firstLane = (uint32_t)__ffsll((long long)mIn) - 1u;
 			QuadStep Q;
 			uint32_t key[4] = { 0, 1, 2, 3 };
-			quadClassify<!ANYHIT>(buf + (nidx & (RT_TREELET_SLOTS - 1)) * 4, T, T.d, tlimit, inSub, cons, info, firstLane, Q, key);
+			quadClassify<!ANYHIT>(buf + (nidx & (RT_QUAD_SLOTS - 1)) * 4, T, T.d, tlimit, inSub, cons, info, firstLane, Q, key);
 			if (COUNT || RT_PROF) T.cntNodes += inSub ? 1u : 0u;
 			if (COUNT) T.cntSteps++;
 			TR(5, __popcll(Q.m[0] | Q.m[1] | Q.m[2] | Q.m[3]));
@@ -688,14 +689,14 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			TR(7, count);
 			const uint32_t key0 = (uint32_t)~node + 1u;
 			if (!longRun && (info & RT_TREELET_EMBED)) {   // ... which arrived with the treelet
-				const float4* q = L.level((info >> 4) & 15u) + (info & 15u) * 4u;
+				const float4* q = L.level((info >> RT_QUAD_SLOT_BITS) & 15u) + (info & (RT_QUAD_SLOTS - 1u)) * 4u;
 				for (uint32_t k = 0; k < count; k++, q += 4) {
 					const float4 a = q[0], b = q[1], c = q[2], d = q[3];
 					packetTri<ANYHIT, COUNT>(S, T, inSub, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), __float_as_uint(d.w));   // slot = triangle, material, index, key
 				}
 			} else {   // ... fetched 16 at a time (64 lanes x 16 B) into the staging buffer
 				const uint32_t first = longRun ? (uint32_t)~node : info & (RT_TREELET_EMBED - 1u);
-				float4* buf = L.treelet + L.staging * 64u;
+				float4* buf = L.treelet + L.staging * (RT_QUAD_SLOTS * 4u);
 				for (uint32_t k0 = 0; k0 < count; k0 += 16u) {
 					const uint32_t nb = count - k0 < 16u ? count - k0 : 16u;
 					if (lane < nb * 4u) buf[lane] = reinterpret_cast<const float4*>(S.tris + first + k0)[lane];
@@ -755,11 +756,12 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 			const bool cons = ((uint32_t)node & RT_TREELET_CONS) != 0u;
 			const int32_t nidx = (int32_t)((uint32_t)node & (RT_TREELET_CONS - 1u));
 			float4* buf = L.level(info);
-			if ((nidx & (RT_TREELET_SLOTS - 1)) == 0 && nidx != 0) {
-				buf[lane] = S.quads[(size_t)nidx * 4 + lane];
+			if ((nidx & (RT_QUAD_SLOTS - 1)) == 0 && nidx != 0) {
+#pragma unroll
+				for (uint32_t k = 0; k < RT_QUAD_SLOTS * 4u; k += 64u) buf[k + lane] = S.quads[(size_t)nidx * 4 + k + lane];
 				__builtin_amdgcn_wave_barrier();
 			}
-			const float4* q = buf + (nidx & (RT_TREELET_SLOTS - 1)) * 4;
+			const float4* q = buf + (nidx & (RT_QUAD_SLOTS - 1)) * 4;
 			const float4 q6 = q[6], q7 = q[7];
 			const int32_t c[4] = { __builtin_amdgcn_readfirstlane(__float_as_int(q6.x)), __builtin_amdgcn_readfirstlane(__float_as_int(q6.y)),
 			                       __builtin_amdgcn_readfirstlane(__float_as_int(q6.z)), __builtin_amdgcn_readfirstlane(__float_as_int(q6.w)) };
@@ -815,7 +817,7 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 			// what only leaves need comes back from LDS (and is dead again after the leaf)
 			A.d = coldLd3(L.cold, COLD_DA); B.d = coldLd3(L.cold, COLD_DB); A.len = L.cold[COLD_LENA * 64]; B.len = L.cold[COLD_LENB * 64];
 			if (!longRun && (info & RT_TREELET_EMBED)) {
-				const float4* q = L.level((info >> 4) & 15u) + (info & 15u) * 4u;
+				const float4* q = L.level((info >> RT_QUAD_SLOT_BITS) & 15u) + (info & (RT_QUAD_SLOTS - 1u)) * 4u;
 				for (uint32_t k = 0; k < count; k++, q += 4) {
 					const float4 a = q[0], b = q[1], c = q[2], d = q[3];
 					packetTri<true, COUNT>(S, A, inA, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), __float_as_uint(d.w), L.cold + COLD_SHA * 64);
@@ -823,7 +825,7 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 				}
 			} else {
 				const uint32_t first = longRun ? (uint32_t)~node : info & (RT_TREELET_EMBED - 1u);
-				float4* buf = L.treelet + L.staging * 64u;
+				float4* buf = L.treelet + L.staging * (RT_QUAD_SLOTS * 4u);
 				for (uint32_t k0 = 0; k0 < count; k0 += 16u) {
 					const uint32_t nb = count - k0 < 16u ? count - k0 : 16u;
 					if (lane < nb * 4u) buf[lane] = reinterpret_cast<const float4*>(S.tris + first + k0)[lane];

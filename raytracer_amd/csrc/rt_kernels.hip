@@ -1175,8 +1175,9 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 // ---------------------------------------------------------------------------------------------------------
 // shade: everything Object::lightPoint does except the shadow rays
 // ---------------------------------------------------------------------------------------------------------
+// (the plain variant fits 64 VGPRs without spilling: 8 waves per SIMD, so that it shares a SIMD with whatever the other lanes run: +1 % on C2)
 template <bool CSG, bool PICK, bool TEXFIX>
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RtQueue rq, RtQueue hq, uint32_t nArg, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
+__global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX) ? 1 : 8) void k_shade(DevScene S, RtQueue rq, RtQueue hq, uint32_t nArg, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
                                                   RtAccum A, uint32_t aaSq, int maxDepth, int wantSurfaces,
                                                   uint8_t* outHit, int32_t* outId, float* outT, RtPick pick, RtTexFix tex) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;

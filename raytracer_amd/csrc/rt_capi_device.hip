@@ -567,13 +567,13 @@ int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std:
 	quadDepth = 0;
 	if (A.root < 0) return 0;
 	struct Entry { float box[6]; int32_t ref; };   // ref >= 0: binary node whose quad this entry leads to; < 0: ~index into A.leaves
-	auto entriesOf = [&](int32_t n, Entry* e) -> int {
+	auto entriesOf = [&](int32_t n, Entry* e, bool skipLevel) -> int {
 		const AugTree::Node& b = A.nodes[(size_t)n];
 		int count = 0;
 		for (int k = 0; k < 2; k++) {
 			const int32_t c = b.child[k];
 			static const uint32_t collapse = envU32("RT_QUAD_COLLAPSE", 3);   // diagnostic: bit 0 reference nodes, bit 1 sub-tree nodes
-			if (c >= 0 && A.nodes[(size_t)c].cons == b.cons && (collapse & (b.cons ? 2u : 1u))) {   // same regime: the child's own box is skipped
+			if (skipLevel && c >= 0 && A.nodes[(size_t)c].cons == b.cons && (collapse & (b.cons ? 2u : 1u))) {   // same regime: the child's own box is skipped
 				const AugTree::Node& m = A.nodes[(size_t)c];
 				for (int j = 0; j < 2; j++) { memcpy(e[count].box, m.box[j], sizeof e[count].box); e[count].ref = m.child[j]; count++; }
 			} else { memcpy(e[count].box, b.box[k], sizeof e[count].box); e[count].ref = c; count++; }
@@ -600,9 +600,16 @@ int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std:
 		auto join = [&](int32_t node, int depth, bool must) {
 			Member m{};
 			m.node = node; m.depth = depth;
-			m.n = entriesOf(node, m.e);
-			uint32_t tris[4] = { 0, 0, 0, 0 }, all = 0;
-			for (int i = 0; i < m.n; i++) if (m.e[i].ref < 0) { tris[i] = embeddable(m.e[i].ref); all += tris[i]; }
+			uint32_t tris[4] = { 0, 0, 0, 0 }, all = 0, mustEmbed = 0;
+			for (int pass = 0; pass < 2; pass++) {
+				m.n = entriesOf(node, m.e, pass == 0);
+				all = 0; mustEmbed = 0;
+				for (int i = 0; i < 4; i++) tris[i] = 0;
+				for (int i = 0; i < m.n; i++) if (m.e[i].ref < 0) { tris[i] = embeddable(m.e[i].ref); all += tris[i]; if (A.leaves[(size_t)~m.e[i].ref].sub) mustEmbed += tris[i]; }
+				// sub-leaves have to sit in their quad's treelet: four of them with four triangles each do not fit beside the quad, so such a
+				// node keeps its two children as entries (each then a quad of two sub-leaves)
+				if (2 + mustEmbed <= RT_QUAD_SLOTS) break;
+			}
 			if (!must && used + 2 + all > RT_QUAD_SLOTS) return false;
 			used += 2;
 			for (int i = 0; i < m.n; i++) {

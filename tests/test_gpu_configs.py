@@ -407,6 +407,23 @@ def test_c5_style_large_mesh_deep_tree(tmp_path):
     sc.close()
 
 
+def test_fat_leaves_of_64_triangles(tmp_path, monkeypatch):
+    """4 193 408 triangles under the depth-capped tree are 65 536 leaves of 63 / 64: their sub-trees have nodes of 13 .. 16 triangles whose
+    four grandchildren are sub-leaves of up to four -- more triangles than fit a treelet beside their quad (such a node keeps its two
+    children as entries).  The packet walk against the per-lane walk on the same frame, bit for bit."""
+    import torch
+    flat = rt.FlatScene.from_json(scenes.c5_scene(str(tmp_path), grid=1448))
+    assert flat.info.n_tris == 2 * 1448 * 1448
+    sc = rt.Scene(flat, 0)
+    W, H = 480, 270
+    cam = rt.Camera(flat.fov, W, H, eye=(0, 1.5, 1.0), rot_x=-0.3)
+    a = sc.render(W, H, camera=cam)
+    monkeypatch.setenv("RT_PACKET_LEVELS", "0")
+    b = sc.render(W, H, camera=cam)
+    assert np.array_equal(bits(a), bits(b))
+    sc.close()
+
+
 def test_c5_full_size_from_a_mesh_file(tmp_path):
     # 4 999 122 triangles through the binary mesh ingest: 65 536 leaves of ~76 triangles (depth cap), which the packet
     # kernels read as long external runs, 16 at a time

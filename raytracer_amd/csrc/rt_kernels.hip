@@ -1008,28 +1008,40 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RtQueue rq, ui
 // handing packets out in a scattered order to avoid neighbouring waves walking the same lines gained only 5 %.
 // Packets are handed out kPacketChunk at a time: packet numbers wave*chunk .. +chunk-1 statically, then chunks from
 // the cursor.  PacketFeed walks through the chunk a wave holds.
-struct PacketFeed { uint32_t next, end; };
+// Static share (round 2): with the quad walk a packet takes ~25 us and the 2 048 waves of a launch came to the cursor 66 times per
+// microsecond, close to what one address serves (~90): every wave's request queued behind the others'.  Now RT_PACKET_STATIC_PCT of
+// the packets are handed out without the cursor -- wave w takes packets w, w + W, w + 2 W, ... (W = waves of the launch; the hand-out
+// order already mixes cheap and expensive packets) -- and only the rest, which evens out the waves' different luck, goes through it.
+// Measured (share 0 / 50 / 75 / 90 %): nearest-hit kernel alone 0.497 / 0.458 / 0.469 / 0.487 ms, shadow kernel ~0.49 ms throughout; with
+// four lanes in flight the frame rate is the same within noise (the other lanes' kernels were filling those waits already).
+#ifndef RT_PACKET_STATIC_PCT
+#define RT_PACKET_STATIC_PCT 50
+#endif
+struct PacketFeed { uint32_t j, S; };   // static packets taken so far / this wave's static share
 __device__ __forceinline__ PacketFeed firstPackets(uint32_t nPackets) {
-	const unsigned long long b = (unsigned long long)waveNumber() * kPacketChunk;
+	const uint32_t W = waveCount();
 	PacketFeed f;
-	f.next = (uint32_t)(b < nPackets ? b : nPackets);
-	f.end = (uint32_t)(b + kPacketChunk < nPackets ? b + kPacketChunk : nPackets);
+	f.j = 0;
+	uint32_t S = (uint32_t)((unsigned long long)nPackets * RT_PACKET_STATIC_PCT / 100u / W);
+	if (S < 1u) S = 1u;
+	f.S = S;
 	return f;
 }
 __device__ __forceinline__ uint32_t fetchPacket(PacketFeed& f, uint32_t* head, uint32_t nPackets) {
-	if (f.next == f.end) {
-		if ((unsigned long long)nPackets <= (unsigned long long)waveCount() * kPacketChunk) return kInactive;   // every packet was handed out statically
-		uint32_t k = 0;
-		if (__lane_id() == 0) k = atomicAdd(head, kPacketChunk);
-		const unsigned long long b = (unsigned long long)__builtin_amdgcn_readfirstlane(k) + (unsigned long long)waveCount() * kPacketChunk;
-		if (b >= nPackets) return kInactive;
-		f.next = (uint32_t)b;
-		f.end = (uint32_t)(b + kPacketChunk < nPackets ? b + kPacketChunk : nPackets);
+	const uint32_t W = waveCount();
+	if (f.j < f.S) {   // (wave-uniform)
+		const unsigned long long b = (unsigned long long)waveNumber() + (unsigned long long)f.j * W;
+		f.j++;
+		if (b < nPackets) return (uint32_t)b;
+		f.j = f.S;
 	}
-	return f.next++;
+	if ((unsigned long long)nPackets <= (unsigned long long)W * f.S) return kInactive;   // every packet was handed out statically
+	uint32_t k = 0;
+	if (__lane_id() == 0) k = atomicAdd(head, 1u);
+	const unsigned long long b = (unsigned long long)__builtin_amdgcn_readfirstlane(k) + (unsigned long long)W * f.S;
+	return b < nPackets ? (uint32_t)b : kInactive;
 }
 
-// Nearest hit for coherent ray sets: one packet = 64 consecutive queue slots (an 8x8 pixel block of the tile order).
 template <bool CSG, bool COUNT>
 __global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_intersect_packet(DevScene S, RtQueue rq, uint32_t nArg, const uint32_t* nDev, RtQueue hq, RtCounters* ctr, uint32_t groupStride) {
 	const uint32_t lane = __lane_id();
@@ -1063,7 +1075,7 @@ __global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_intersect_
 		return r;
 	};
 	PacketFeed feed = firstPackets(nPackets);
-	uint32_t pk = permute(feed.next < feed.end ? feed.next++ : kInactive);
+	uint32_t pk = permute(fetchPacket(feed, &ctr->head_nearest, nPackets));
 	while (pk != kInactive) {
 		TR(1, pk);
 		const Rays cur = loadRays(pk);
@@ -1499,7 +1511,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW_WAVES_PER_SIMD) void k_shadow_poi
 		return p;
 	};
 	PacketFeed feed = firstPackets(totalPackets);
-	uint32_t q = feed.next < feed.end ? feed.next++ : kInactive;
+	uint32_t q = fetchPacket(feed, head, totalPackets);
 	while (q != kInactive) {
 		TR(1, q);
 		const f3 p = loadPoint(q);
@@ -1547,7 +1559,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW2_WAVES_PER_SIMD) void k_shadow_po
 	const uint32_t totalPackets = ((nsurf + 63u) / 64u) * nPairs;
 	unsigned long long cn = 0, cp = 0, cs = 0;
 	PacketFeed feed = firstPackets(totalPackets);
-	uint32_t q = feed.next < feed.end ? feed.next++ : kInactive;
+	uint32_t q = fetchPacket(feed, &ctr->head_shadow, totalPackets);
 	while (q != kInactive) {
 		const uint32_t s = (q / nPairs) * 64u + lane;
 		const int lightA = lightList[2u * (q % nPairs)], lightB = lightList[2u * (q % nPairs) + 1u];

@@ -691,6 +691,12 @@ struct Run {
 
 	// Which traversal form a level uses.  Level 0 of a frame (and its shadow rays) is coherent by construction: 64
 	// consecutive queue slots are an 8x8 pixel block.  Deeper levels and caller-supplied rays are walked per lane.
+	// RT_PACKET_LEVELS > 1 sends deeper levels through the packet kernels as well: 64 consecutive children in the order the shading
+	// kernel compacted them, i.e. still neighbours in the image.  Measured (profiles/r02_deeper_levels.txt) and not the default: the
+	// bundled scenes move by -8 .. +5 % (i, a mesh under two spheres: 0.36 -> 0.34 ms), the CSG lattice C3 loses (2.35 -> 2.57 ms with
+	// level 1 in packets, 4.2 ms with all levels: a CSG leaf is evaluated by the lanes that reach it while the rest of the packet
+	// waits), and a reflective 100 352-triangle height field at 1080p, whose reflected rays leave neighbouring triangles in different
+	// directions, takes 4.3 ms per lane walk against 7.9 ms in packets.
 	int packetLevels = (int)envU32("RT_PACKET_LEVELS", 1);
 	// (RT_PACKET_BATCHES: caller-supplied rays go through the packet kernels too, 64 consecutive rays per packet -- what the tests use to
 	// compare the two walks on the same rays; read per call)
@@ -821,7 +827,7 @@ struct Run {
 				for (int k = read; k < lv; k++) bound = std::min<uint64_t>(bound * fan, sc->qcap);
 				const uint32_t nb = (uint32_t)std::min<uint64_t>(bound, sc->qcap);
 				const uint32_t* nDev = lv == 0 ? nullptr : &L[lv - 1].next_count;
-				const bool packets = coherent(lv) && lv == 0;
+				const bool packets = coherent(lv);
 				rtk_intersect(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketNear : sc->maxBlocks, ln->ray[cur], nb, ln->hitq, &L[lv], nDev);
 				rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, nb, ln->ray[cur ^ 1], ln->surfq, ln->transq, &L[lv], sc->accum, aaSq, maxDepth,
 				          shadows, lv == 0 ? src.outHit : nullptr, src.outId, src.outT, pick, sc->texFix(*ln), nDev);

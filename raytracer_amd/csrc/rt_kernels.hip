@@ -268,8 +268,14 @@ __device__ __forceinline__ void travInit(const DevScene& S, Trav& T, f3 e, f3 d)
 		}
 	} else T.len = length(d);
 	if (S.root_child < 0 && S.root_count == 0) return;
-	const float tr = boxIntersect(S.root_box, e, d, false);   // the root's own box (bvh.cpp:97-100 / 131-134), exact
-	if (tr < 0 || tr > (ANYHIT ? 1.0f : T.tmin)) return;
+	// the root's own box (bvh.cpp:97-100 / 131-134): the multiply test the children get, the six exact divides only when it cannot tell
+	float tEntry;
+	const int cls = boxClassify(S.root_box, e, T.inv, T.special, ANYHIT ? 1.0f : T.tmin, tEntry);
+	if (cls == 0) return;
+	if (cls == 2) {
+		const float tr = boxIntersect(S.root_box, e, d, false);
+		if (tr < 0 || tr > (ANYHIT ? 1.0f : T.tmin)) return;
+	}
 	T.cur = S.treelet_root;   // slot 0 of treelet 0, or the one leaf of a one-leaf tree
 	T.aux = S.treelet_root_aux; T.base = 0;
 }
@@ -1053,8 +1059,9 @@ __global__ __launch_bounds__(kBlock, RT_PACKET_WAVES_PER_SIMD) void k_intersect_
 	// the cursor's pace.  Strided, cheap and expensive packets are in flight together all the time.
 	const uint32_t nGroups = ((n + 63u) / 64u + kPacketGroup - 1u) / kPacketGroup;
 	const uint32_t nPackets = nGroups * kPacketGroup;   // the last group may hold empty packets
+	// (groupStride 0: in order -- the launches of deeper levels, whose ray count only the device knows; no sky stretches there)
 	auto permute = [&](uint32_t k) {
-		if (k == kInactive) return k;
+		if (k == kInactive || groupStride == 0u) return k;
 		const uint32_t g = (uint32_t)(((unsigned long long)(k / kPacketGroup) * groupStride) % nGroups);
 		return g * kPacketGroup + k % kPacketGroup;
 	};
@@ -1928,8 +1935,8 @@ static uint32_t coprimeStride(uint32_t groups) {
 	return s % groups ? s % groups : 1;
 }
 void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue rq, uint32_t n, RtQueue hq, RtCounters* ctr, const uint32_t* nDev) {
-	if (coherent) {   // (only ever with an exact n: the hand-out stride is computed from it)
-		const uint32_t stride = coprimeStride(((n + 63u) / 64u + kPacketGroup - 1u) / kPacketGroup);
+	if (coherent) {   // (the strided hand-out order needs the exact n: with a count on the device, n is a bound and the packets go out in order)
+		const uint32_t stride = nDev ? 0u : coprimeStride(((n + 63u) / 64u + kPacketGroup - 1u) / kPacketGroup);
 		if (csg) { if (count) RT_LAUNCH_PS((k_intersect_packet<true, true>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, nDev, hq, ctr, stride); else RT_LAUNCH_PS((k_intersect_packet<true, false>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, nDev, hq, ctr, stride); }
 		else { if (count) RT_LAUNCH_PS((k_intersect_packet<false, true>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, nDev, hq, ctr, stride); else RT_LAUNCH_PS((k_intersect_packet<false, false>), n, maxBlocks, packetLdsBytes(S), st, S, rq, n, nDev, hq, ctr, stride); }
 		return;

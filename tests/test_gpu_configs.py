@@ -424,6 +424,53 @@ def test_fat_leaves_of_64_triangles(tmp_path, monkeypatch):
     sc.close()
 
 
+@pytest.mark.parametrize("textured", [False, True])
+def test_deeper_levels_in_packets(tmp_path, monkeypatch, textured):
+    """RT_PACKET_LEVELS > 1 sends the deeper levels of the ray tree through the packet kernels too (64 consecutive children of the level
+    above per packet; not the default, see Run::packetLevels).  A mirror-like height field under a mirror sphere and a glass sphere:
+    the frame with every level in packets against the oracle, and against the default frame and the all-per-lane frame bit for bit.
+    Untextured: the level loop that runs ahead of the host (packet launches sized by a bound, counts read on the device); textured
+    and reflective: the loop that reads the counts back after every level (texel records)."""
+    import json
+    src = scenes.c2_scene(str(tmp_path), grid=64)
+    with open(src) as f:
+        doc = json.load(f)
+    mesh, s1, s2 = doc["objects"][:3]
+    if not textured:
+        mesh["type"] = "mesh"
+        mesh.pop("texture"); mesh.pop("uvCoords")
+        mesh["material"]["diffuse"] = [0.5, 0.6, 0.4]
+    mesh["material"]["reflective"] = [0.4, 0.4, 0.4]
+    for sph in (s1, s2):
+        sph["type"] = "sphere"
+        sph.pop("bumpmap"); sph.pop("bumpdepth")
+    s1["material"]["reflective"] = [0.5, 0.5, 0.5]
+    s2["material"]["transmissive"] = [0.6, 0.6, 0.6]
+    s2["material"]["refraction"] = 1.3
+    path = str(tmp_path / f"mirror_field_{int(textured)}.json")
+    with open(path, "w") as f:
+        json.dump(doc, f)
+    flat = rt.FlatScene.from_json(path)
+    sc = rt.Scene(flat, 0)
+    W, H = 320, 180
+    cam = rt.Camera(flat.fov, W, H, eye=(0, 1.5, 1.0), rot_x=-0.3)
+    monkeypatch.setenv("RT_PACKET_LEVELS", "8")
+    a = sc.render(W, H, camera=cam, max_depth=6)
+    st = dict(sc.last_stats)
+    assert st["levels"] == 7
+    ref, nn, ns = oracle.render(flat, cam, W, H, max_depth=6, seed=1, threads=8)
+    assert st["rays_nearest"] == nn and st["rays_shadow"] == ns
+    assert np.abs(rgb8(a).astype(int) - rgb8(ref).astype(int)).max() <= 1
+    monkeypatch.delenv("RT_PACKET_LEVELS")
+    b = sc.render(W, H, camera=cam, max_depth=6)
+    assert sc.last_stats["rays_nearest"] == nn
+    assert np.array_equal(bits(a), bits(b))
+    monkeypatch.setenv("RT_PACKET_LEVELS", "0")
+    c = sc.render(W, H, camera=cam, max_depth=6)
+    assert np.array_equal(bits(a), bits(c))
+    sc.close()
+
+
 def test_c5_full_size_from_a_mesh_file(tmp_path):
     # 4 999 122 triangles through the binary mesh ingest: 65 536 leaves of ~76 triangles (depth cap), which the packet
     # kernels read as long external runs, 16 at a time

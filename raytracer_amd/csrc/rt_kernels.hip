@@ -169,8 +169,9 @@ __device__ __forceinline__ NodeRegs loadNode(const rt_bvh_node* n) {   // one 64
 // ---------------------------------------------------------------------------------------------------------
 // Node test.  BoundingBox::intersect (objects.cpp:11-44) divides six times per box; on the device a correctly
 // rounded fp32 divide is ~11 VALU instructions, which made the two-box node test ~2/3 of all instructions.
-// Here the slabs are first evaluated with one multiply by the ray's precomputed 1/d.  Those t values are within 2 ulp
-// of the reference's, so every decision taken with a relative margin of 1e-6 is the reference's decision; only when
+// Here the slabs are first evaluated with one multiply by the ray's precomputed 1/d.  Those t values are within 3 ulp
+// of the reference's (the subtraction, a reciprocal good to 1 ulp, the product), so every decision taken with a relative margin of 1e-6
+// (8 ulp) is the reference's decision; only when
 // tnear / tfar / t_limit are closer than the margin is the exact divide-based test evaluated (rare, divergent:
 // 5 380 of 72 M tests on the C2 frame).  The hit condition of the reference, "tnear <= tfar, tfar >= 0, entry <=
 // limit" (entry = tnear, or 0 from inside the box), is tnear <= min(tfar, limit) and tfar >= 0; the sign of tfar
@@ -250,7 +251,10 @@ struct Trav {
 template <bool ANYHIT>
 __device__ __forceinline__ void travInit(const DevScene& S, Trav& T, f3 e, f3 d) {
 	T.e = e; T.d = d;
-	T.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	// (1/d only feeds the multiply tests, whose margin of 1e-6 covers a reciprocal good to 1 ulp: v_rcp_f32, one instruction where the
+	// correctly rounded divide takes eleven; a zero or denormal component gives an infinite or huge value and `special` sends the ray's
+	// boxes to the exact test)
+	T.inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
 	T.special = !(fabsf(T.inv.x) <= 3.0e38f && fabsf(T.inv.y) <= 3.0e38f && fabsf(T.inv.z) <= 3.0e38f);
 	T.sp = 0; T.cur = kEmpty;
 	T.cntNodes = 0; T.cntPrims = 0; T.cntSteps = 0;
@@ -1618,6 +1622,21 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW2_WAVES_PER_SIMD) void k_shadow_po
 	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); if (lane == 0) atomicAdd(&ctr->steps_shadow, cs); }
 }
 
+// Sum of a value over the wave, delivered in lane 63: xor-butterflies inside each row of 16 lanes (quad_perm, row_half_mirror,
+// row_mirror), then lane 15 of each row added into the next row and lane 31 into the upper half (row_bcast).  Additions pair
+// neighbours, then neighbouring pairs, ...: the tree a Hillis-Steele scan builds for its last lane.
+#define RT_DPP_ADD(v, ctrl, rows) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xf, false))
+__device__ __forceinline__ float waveSumToLane63(float v) {
+	RT_DPP_ADD(v, 0xB1, 0xf);    // quad_perm:[1,0,3,2]
+	RT_DPP_ADD(v, 0x4E, 0xf);    // quad_perm:[2,3,0,1]
+	RT_DPP_ADD(v, 0x141, 0xf);   // row_half_mirror
+	RT_DPP_ADD(v, 0x140, 0xf);   // row_mirror
+	RT_DPP_ADD(v, 0x142, 0xa);   // row_bcast:15, into rows 1 and 3
+	RT_DPP_ADD(v, 0x143, 0xc);   // row_bcast:31, into rows 2 and 3
+	return v;
+}
+#undef RT_DPP_ADD
+
 // Rectangular / circular area light `lightIndex`: one lane per (surface, sample), samples of one surface in
 // consecutive lanes (their rays leave the same point towards neighbouring targets), summed across lanes by a
 // segmented shuffle scan so each surface costs one atomic per wave instead of one per sample.
@@ -1666,15 +1685,22 @@ __global__ __launch_bounds__(kBlock, RT_AREA_WAVES_PER_SIMD) void k_shadow_area(
 			c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
 		}
 	}
-	// segmented inclusive scan over the wave, key = surface
 	const uint32_t lane = __lane_id();
+	uint32_t nextKey = s;
+	if ((ns & 63u) == 0u) {
+		// a multiple of 64 samples: the wave is one surface and lane 63 gets the sum through the DPP network instead of 24 LDS
+		// permutes -- the same balanced tree of additions over the lanes in order as the scan below, so the same bits
+		c.x = waveSumToLane63(c.x); c.y = waveSumToLane63(c.y); c.z = waveSumToLane63(c.z);
+	} else {
+		// segmented inclusive scan over the wave, key = surface
 #pragma unroll
-	for (int off = 1; off < 64; off <<= 1) {
-		const uint32_t ks2 = __shfl_up(s, off);
-		const float ax = __shfl_up(c.x, off), ay = __shfl_up(c.y, off), az = __shfl_up(c.z, off);
-		if (lane >= (uint32_t)off && ks2 == s) { c.x += ax; c.y += ay; c.z += az; }
+		for (int off = 1; off < 64; off <<= 1) {
+			const uint32_t ks2 = __shfl_up(s, off);
+			const float ax = __shfl_up(c.x, off), ay = __shfl_up(c.y, off), az = __shfl_up(c.z, off);
+			if (lane >= (uint32_t)off && ks2 == s) { c.x += ax; c.y += ay; c.z += az; }
+		}
+		nextKey = __shfl_down(s, 1);
 	}
-	const uint32_t nextKey = __shfl_down(s, 1);
 	if (live && (lane == 63u || nextKey != s)) {   // arealight.cpp:21
 		w = mk3(qf(sq, SQ_WR, s), qf(sq, SQ_WG, s), qf(sq, SQ_WB, s));
 		pixKey = qu(sq, SQ_PIX, s);

@@ -98,6 +98,49 @@ __device__ __forceinline__ void accumAdd2(const RtAccum& A, uint32_t pixel, f3 c
 	}
 }
 
+// One or two contributions per lane, for frames with several samples per pixel: their samples are neighbours in the queues, so sixteen
+// lanes of a wave would send their atomics to the same three addresses, which take them one after the other (C5, 16 samples per pixel:
+// the shading kernel spent two thirds of its time there).  Lanes of a row of 16 that follow each other with the same pixel add their
+// fixed-point values first (integers: the accumulator ends up with the same bits as after the separate atomics) and the last lane of
+// each run sends the sum.  Must be reached by every lane of the wave.
+__device__ __forceinline__ long long accumFixed(float c) {
+	if (c == 0.0f) return 0;
+	double v = (double)c * 4294967296.0;
+	if (v > 4.0e18) v = 4.0e18;
+	if (v < -4.0e18) v = -4.0e18;
+	return __double2ll_rn(v);
+}
+#define RT_ROW_SHR(x, n) __builtin_amdgcn_update_dpp(0, (int)(x), 0x110 + (n), 0xf, 0xf, false)
+__device__ __forceinline__ void accumAddRows(const RtAccum& A, uint32_t pixel, f3 c1, bool has1, f3 c2, bool has2) {
+	const bool ok1 = has1 && isfinite(c1.x) && isfinite(c1.y) && isfinite(c1.z), ok2 = has2 && isfinite(c2.x) && isfinite(c2.y) && isfinite(c2.z);
+	if ((has1 && !ok1) || (has2 && !ok2)) A.nonfinite[pixel] = 1;
+	long long v[3];
+	v[0] = (ok1 ? accumFixed(c1.x) : 0) + (ok2 ? accumFixed(c2.x) : 0);
+	v[1] = (ok1 ? accumFixed(c1.y) : 0) + (ok2 ? accumFixed(c2.y) : 0);
+	v[2] = (ok1 ? accumFixed(c1.z) : 0) + (ok2 ? accumFixed(c2.z) : 0);
+	const uint32_t lane = __lane_id();
+	const uint32_t prev = (uint32_t)RT_ROW_SHR(pixel, 1);
+	const unsigned long long heads = __ballot((lane & 15u) == 0u || prev != pixel);   // (rows start runs)
+	const uint32_t start = 63u - (uint32_t)__clzll((long long)(heads & ((2ull << lane) - 1ull)));
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		uint32_t lo = (uint32_t)v[k], hi = (uint32_t)((unsigned long long)v[k] >> 32);
+		// inclusive sum over the lanes of the run up to this one: steps of 1, 2, 4, 8 inside the row
+#define RT_ROW_STEP(n) { const uint32_t l2 = (uint32_t)RT_ROW_SHR(lo, n), h2 = (uint32_t)RT_ROW_SHR(hi, n); \
+			if (lane >= start + (n)) { const unsigned long long t = (((unsigned long long)hi << 32) | lo) + (((unsigned long long)h2 << 32) | l2); lo = (uint32_t)t; hi = (uint32_t)(t >> 32); } }
+		RT_ROW_STEP(1) RT_ROW_STEP(2) RT_ROW_STEP(4) RT_ROW_STEP(8)
+#undef RT_ROW_STEP
+		v[k] = (long long)(((unsigned long long)hi << 32) | lo);
+	}
+	const bool tail = lane == 63u || ((heads >> (lane + 1u)) & 1ull) != 0ull;
+	if (tail) {
+#pragma unroll
+		for (int k = 0; k < 3; k++)
+			if (v[k] != 0) atomicAdd(A.rgb + (size_t)k * A.npix + pixel, (unsigned long long)v[k]);
+	}
+}
+#undef RT_ROW_SHR
+
 // local pixel number (tile-major, 8x8 blocks inside a 32x8 tile) -> image coordinates
 __device__ __forceinline__ bool tilePixel(uint32_t lp, int W, int H, int rank, int ranks, int& x, int& y) {
 	const uint32_t tilesX = (uint32_t)(W + 31) / 32, tilesY = (uint32_t)(H + 7) / 8;
@@ -1199,8 +1242,9 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 // shade: everything Object::lightPoint does except the shadow rays
 // ---------------------------------------------------------------------------------------------------------
 // (the plain variant fits 64 VGPRs without spilling: 8 waves per SIMD, so that it shares a SIMD with whatever the other lanes run: +1 % on C2)
-template <bool CSG, bool PICK, bool TEXFIX>
-__global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX) ? 1 : 8) void k_shade(DevScene S, RtQueue rq, RtQueue hq, uint32_t nArg, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
+// MULTI: several samples per pixel -- the accumulator atomics of neighbouring lanes are combined first (accumAddRows)
+template <bool CSG, bool PICK, bool TEXFIX, bool MULTI>
+__global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX || MULTI) ? 1 : 8) void k_shade(DevScene S, RtQueue rq, RtQueue hq, uint32_t nArg, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
                                                   RtAccum A, uint32_t aaSq, int maxDepth, int wantSurfaces,
                                                   uint8_t* outHit, int32_t* outId, float* outT, RtPick pick, RtTexFix tex) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -1223,7 +1267,11 @@ __global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX) ? 1 : 8) void k_sha
 		if (outId) outId[pixKey] = hit ? primId(S, prim) : -1;
 		if (outT) outT[pixKey] = hit ? t : 0.0f;
 	}
-	if (live && !hit) accumAdd(A, pixel, w * background);   // q1.cpp:143-145 / objects.cpp:68-69,94-95
+	// what this ray adds to its pixel by itself: the background it ran into (q1.cpp:143-145 / objects.cpp:68-69,94-95) or the ambient
+	// term of its hit, and the background a reflected ray beyond the depth limit would have fetched; sent at the end of the kernel
+	f3 own = w * background, beyond = mk3(0, 0, 0);
+	bool hasOwn = live && !hit, hasBeyond = false;
+	if (!MULTI && hasOwn) accumAdd(A, pixel, own);
 	if (PICK && live && !hit && path > 1u) pickEmit(pick, path, RT_PICK_MISS, 0, 0, mk3(0, 0, 0));
 
 	bool wantR = false, wantX = false, wantS = false;
@@ -1276,7 +1324,7 @@ __global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX) ? 1 : 8) void k_sha
 		f3 amb = mk3(0, 0, 0);
 		for (int l = 0; l < S.n_lights; l++)
 			if (S.lights[l].type == RT_LIGHT_AMBIENT) amb = amb + ld3(S.lights[l].colour) * ld3(ka);
-		accumAdd(A, pixel, wl * amb);
+		if (MULTI) { own = wl * amb; hasOwn = true; } else accumAdd(A, pixel, wl * amb);
 
 		if (!isZero3(m.reflective)) {   // objects.cpp:62-75
 			const f3 R = reflectRay(V, N);
@@ -1284,7 +1332,7 @@ __global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX) ? 1 : 8) void k_sha
 			rD = (p + R) - rO;
 			rW = wl * ld3(m.reflective);
 			if (depth + 1 > maxDepth) {   // raytracer.cpp:308-313 -> objects.cpp:68-69
-				accumAdd(A, pixel, rW * background);
+				if (MULTI) { beyond = rW * background; hasBeyond = true; } else accumAdd(A, pixel, rW * background);
 				if (PICK) pickEmit(pick, path * 2u, RT_PICK_MAXDEPTH, 0, 0, mk3(0, 0, 0));
 			} else wantR = true;
 		}
@@ -1368,6 +1416,7 @@ __global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX) ? 1 : 8) void k_sha
 			qsu(sq, SQ_PIX, ss, pixKey); qsu(sq, SQ_PATH, ss, path);
 		} else ctr->overflow = 1;
 	}
+	if (MULTI) accumAddRows(A, pixel, own, hasOwn, beyond, hasBeyond);
 }
 
 // Transmitted rays (objects.cpp:81-104): one request per lane.  The launch covers the most requests the level could have
@@ -1561,7 +1610,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW_WAVES_PER_SIMD) void k_shadow_poi
 
 // Two lights per packet (packetTraverse2): lights lightList[2j] and lightList[2j + 1] for the same 64 surfaces; the surface
 // record is read once and the two contributions reach the pixel as one atomic per channel.
-template <bool CSG, bool COUNT>
+template <bool CSG, bool COUNT, bool MULTI>
 __global__ __launch_bounds__(kBlock, RT_SHADOW2_WAVES_PER_SIMD) void k_shadow_point_packet2(DevScene S, RtQueue sq, uint32_t nsurfArg, const int32_t* lightList, uint32_t nPairs,
                                                                  RtAccum A, uint32_t aaSq, RtCounters* ctr, int countOnDevice) {
 	const uint32_t nsurf = countOnDevice ? (ctr->surf_count < sq.cap ? ctr->surf_count : sq.cap) : nsurfArg;
@@ -1594,29 +1643,58 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW2_WAVES_PER_SIMD) void k_shadow_po
 		TA.shadow = coldLd3(ws.cold, COLD_SHA); TB.shadow = coldLd3(ws.cold, COLD_SHB);
 		q = fetchPacket(feed, &ctr->head_shadow, totalPackets);
 		if (COUNT) { cn += TA.cntNodes + TB.cntNodes; cp += TA.cntPrims + TB.cntPrims; cs += 2u * TA.cntSteps; }   // a step of the two-ray walk serves two rays per lane
-		if (alive && (TA.lit || TB.lit)) {
-			const Surface sf = loadSurface(sq, s);
+		if constexpr (!MULTI) {
+			if (alive && (TA.lit || TB.lit)) {
+				const Surface sf = loadSurface(sq, s);
+				f3 cA = mk3(0, 0, 0), cB = cA;
+				bool hasA = false, hasB = false;
+				if (TA.lit) {
+					const rt_light L = S.lights[lightA];
+					f3 Ld, lightPos;
+					pointLightGeometry(L, sf.p, Ld, lightPos);
+					if (!(L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff))) {   // objects.cpp:451
+						cA = sf.w * phong(ld3(L.colour) * TA.shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
+						hasA = true;
+					}
+				}
+				if (TB.lit) {
+					const rt_light L = S.lights[lightB];
+					f3 Ld, lightPos;
+					pointLightGeometry(L, sf.p, Ld, lightPos);
+					if (!(L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff))) {
+						cB = sf.w * phong(ld3(L.colour) * TB.shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
+						hasB = true;
+					}
+				}
+				accumAdd2(A, sf.pixKey / aaSq, cA, hasA, cB, hasB);
+			}
+		} else {
 			f3 cA = mk3(0, 0, 0), cB = cA;
 			bool hasA = false, hasB = false;
-			if (TA.lit) {
-				const rt_light L = S.lights[lightA];
-				f3 Ld, lightPos;
-				pointLightGeometry(L, sf.p, Ld, lightPos);
-				if (!(L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff))) {   // objects.cpp:451
-					cA = sf.w * phong(ld3(L.colour) * TA.shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
-					hasA = true;
+			uint32_t pixel = 0xffffffffu - lane;   // (MULTI: lanes with nothing to add are runs of their own)
+			if (alive && (TA.lit || TB.lit)) {
+				const Surface sf = loadSurface(sq, s);
+				pixel = sf.pixKey / aaSq;
+				if (TA.lit) {
+					const rt_light L = S.lights[lightA];
+					f3 Ld, lightPos;
+					pointLightGeometry(L, sf.p, Ld, lightPos);
+					if (!(L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff))) {   // objects.cpp:451
+						cA = sf.w * phong(ld3(L.colour) * TA.shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
+						hasA = true;
+					}
+				}
+				if (TB.lit) {
+					const rt_light L = S.lights[lightB];
+					f3 Ld, lightPos;
+					pointLightGeometry(L, sf.p, Ld, lightPos);
+					if (!(L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff))) {
+						cB = sf.w * phong(ld3(L.colour) * TB.shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
+						hasB = true;
+					}
 				}
 			}
-			if (TB.lit) {
-				const rt_light L = S.lights[lightB];
-				f3 Ld, lightPos;
-				pointLightGeometry(L, sf.p, Ld, lightPos);
-				if (!(L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff))) {
-					cB = sf.w * phong(ld3(L.colour) * TB.shadow, sf.kd, sf.ks, sf.shininess, sf.N, Ld, sf.V);
-					hasB = true;
-				}
-			}
-			accumAdd2(A, sf.pixKey / aaSq, cA, hasA, cB, hasB);
+			accumAddRows(A, pixel, cA, hasA, cB, hasB);   // (several samples per pixel: neighbouring lanes add up first)
 		}
 	}
 	if (COUNT) { atomicAdd(&ctr->nodes_shadow, cn); atomicAdd(&ctr->prims_shadow, cp); if (lane == 0) atomicAdd(&ctr->steps_shadow, cs); }
@@ -1977,19 +2055,22 @@ void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue 
                uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick, RtTexFix tex, const uint32_t* nDev) {
 	if (pick.ev) {   // rt_trace_pick: the variants that narrate
 		if (tex.rec) {
-			if (csg) RT_LAUNCH((k_shade<true, true, true>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
-			else RT_LAUNCH((k_shade<false, true, true>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
-		} else if (csg) RT_LAUNCH((k_shade<true, true, false>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
-		else RT_LAUNCH((k_shade<false, true, false>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+			if (csg) RT_LAUNCH((k_shade<true, true, true, false>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+			else RT_LAUNCH((k_shade<false, true, true, false>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+		} else if (csg) RT_LAUNCH((k_shade<true, true, false, false>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+		else RT_LAUNCH((k_shade<false, true, false, false>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
 		return;
 	}
+#define RT_SHADE(...) RT_LAUNCH((k_shade<__VA_ARGS__>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex)
+	const bool multi = aaSq > 1;   // several samples per pixel: the variants that combine their accumulator atomics
 	if (tex.rec) {   // scenes with reflective textured triangles
-		if (csg) RT_LAUNCH((k_shade<true, false, true>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
-		else RT_LAUNCH((k_shade<false, false, true>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+		if (csg) { if (multi) RT_SHADE(true, false, true, true); else RT_SHADE(true, false, true, false); }
+		else { if (multi) RT_SHADE(false, false, true, true); else RT_SHADE(false, false, true, false); }
 		return;
 	}
-	if (csg) RT_LAUNCH((k_shade<true, false, false>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
-	else RT_LAUNCH((k_shade<false, false, false>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex);
+	if (csg) { if (multi) RT_SHADE(true, false, false, true); else RT_SHADE(true, false, false, false); }
+	else { if (multi) RT_SHADE(false, false, false, true); else RT_SHADE(false, false, false, false); }
+#undef RT_SHADE
 }
 void rtk_texel_fix(hipStream_t st, const DevScene& S, bool csg, RtTexFix tex, uint32_t count, RtCounters* ctr, RtAccum A, uint32_t aaSq, uint32_t seed, bool apply) {
 	if (!tex.rec || count == 0) return;
@@ -2028,8 +2109,15 @@ void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, b
 			if (csg) { if (count) RT_LAUNCH_PS((k_shadow_point_packet<true, true>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); else RT_LAUNCH_PS((k_shadow_point_packet<true, false>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); }
 			else { if (count) RT_LAUNCH_PS((k_shadow_point_packet<false, true>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); else RT_LAUNCH_PS((k_shadow_point_packet<false, false>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); }
 		}
-		if (csg) { if (count) RT_LAUNCH_PS((k_shadow_point_packet2<true, true>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S) + (RT_BLOCK / 64) * RT_PACKET_COLD_BYTES, st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet2<true, false>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S) + (RT_BLOCK / 64) * RT_PACKET_COLD_BYTES, st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); }
-		else { if (count) RT_LAUNCH_PS((k_shadow_point_packet2<false, true>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S) + (RT_BLOCK / 64) * RT_PACKET_COLD_BYTES, st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); else RT_LAUNCH_PS((k_shadow_point_packet2<false, false>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S) + (RT_BLOCK / 64) * RT_PACKET_COLD_BYTES, st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod); }
+#define RT_PAIRS(...) RT_LAUNCH_PS((k_shadow_point_packet2<__VA_ARGS__>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S) + (RT_BLOCK / 64) * RT_PACKET_COLD_BYTES, st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod)
+		if (aaSq > 1) {   // several samples per pixel: the variants that combine their accumulator atomics (accumAddRows)
+			if (csg) { if (count) RT_PAIRS(true, true, true); else RT_PAIRS(true, false, true); }
+			else { if (count) RT_PAIRS(false, true, true); else RT_PAIRS(false, false, true); }
+		} else {
+			if (csg) { if (count) RT_PAIRS(true, true, false); else RT_PAIRS(true, false, false); }
+			else { if (count) RT_PAIRS(false, true, false); else RT_PAIRS(false, false, false); }
+		}
+#undef RT_PAIRS
 		return;
 	}
 	if (coherent) {

@@ -291,13 +291,15 @@ struct Trav {
 #endif
 };
 
-template <bool ANYHIT>
+template <bool ANYHIT, bool RCP = true>
 __device__ __forceinline__ void travInit(const DevScene& S, Trav& T, f3 e, f3 d) {
 	T.e = e; T.d = d;
 	// (1/d only feeds the multiply tests, whose margin of 1e-6 covers a reciprocal good to 1 ulp: v_rcp_f32, one instruction where the
 	// correctly rounded divide takes eleven; a zero or denormal component gives an infinite or huge value and `special` sends the ray's
 	// boxes to the exact test)
-	T.inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+	// (RCP false, the two-ray shadow kernel: with this and the root test below the allocator takes 164 registers instead of 156, and two
+	// nearest-hit waves no longer fit on a SIMD beside two of its waves: C2 frame rate -1.6 % with all lanes running)
+	T.inv = RCP ? mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)) : mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 	T.special = !(fabsf(T.inv.x) <= 3.0e38f && fabsf(T.inv.y) <= 3.0e38f && fabsf(T.inv.z) <= 3.0e38f);
 	T.sp = 0; T.cur = kEmpty;
 	T.cntNodes = 0; T.cntPrims = 0; T.cntSteps = 0;
@@ -1632,9 +1634,9 @@ __global__ __launch_bounds__(kBlock, RT_SHADOW2_WAVES_PER_SIMD) void k_shadow_po
 		if (alive) {
 			f3 Ld, lightPos;
 			pointLightGeometry(S.lights[lightA], p, Ld, lightPos);
-			travInit<true>(S, TA, p, lightPos - p);   // bvh.cpp:124
+			travInit<true, false>(S, TA, p, lightPos - p);   // bvh.cpp:124
 			pointLightGeometry(S.lights[lightB], p, Ld, lightPos);
-			travInit<true>(S, TB, p, lightPos - p);
+			travInit<true, false>(S, TB, p, lightPos - p);
 			coldSt3(ws.cold, COLD_DA, TA.d); coldSt3(ws.cold, COLD_DB, TB.d);
 			ws.cold[COLD_LENA * 64] = TA.len; ws.cold[COLD_LENB * 64] = TB.len;
 		}

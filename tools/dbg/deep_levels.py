@@ -25,9 +25,8 @@ with tempfile.TemporaryDirectory() as tmp:
     W, H = 1920, 1080
     cam = rt.Camera(flat.fov, W, H, eye=(0, 1.5, 1.0), rot_x=-0.3)
     frame = torch.zeros(H, W, 3, device="cuda")
-    for levels in ("default", "1", "2", "0"):
-        if levels == "default": os.environ.pop("RT_PACKET_LEVELS", None)
-        else: os.environ["RT_PACKET_LEVELS"] = levels
+    for levels in ("8", "1", "2", "0"):
+        os.environ["RT_PACKET_LEVELS"] = levels
         sc.render_into(frame.data_ptr(), W, H, camera=cam, max_depth=6)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10):

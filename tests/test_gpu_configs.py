@@ -471,6 +471,27 @@ def test_deeper_levels_in_packets(tmp_path, monkeypatch, textured):
     sc.close()
 
 
+@pytest.mark.parametrize("aa", [(2, 1), (2, 2), (4, 4), (3, 5)])
+def test_row_sums_of_multi_sample_frames_are_exact(tmp_path, monkeypatch, gpu_scenes, aa):
+    """Frames with several samples per pixel add the fixed-point contributions of neighbouring lanes before the accumulator atomics
+    (accumAddRows: the shading kernel and the two-light shadow kernel).  Integer sums, so the frame must equal, bit for bit, the one
+    rendered with one atomic per contribution (RT_NO_ROW_SUMS): the bench scene at a small size (two point-type lights, runs of
+    samples broken by misses), the mirror box of scene a (17 levels: children of one pixel scattered over the queues) and a frame
+    whose width leaves partial tiles."""
+    flat = rt.FlatScene.from_json(scenes.c2_scene(str(tmp_path), grid=48))
+    sc = rt.Scene(flat, 0)
+    cases = [(sc, 200, 120, dict(camera=rt.Camera(flat.fov, 200, 120, eye=(0, 1.5, 1.0), rot_x=-0.3))), (gpu_scenes("a"), 160, 120, {}), (gpu_scenes("h"), 75, 41, {})]
+    for scene, W, H, kw in cases:
+        monkeypatch.delenv("RT_NO_ROW_SUMS", raising=False)
+        a = scene.render(W, H, aa=aa, **kw)
+        rays = (scene.last_stats["rays_nearest"], scene.last_stats["rays_shadow"])
+        monkeypatch.setenv("RT_NO_ROW_SUMS", "1")
+        b = scene.render(W, H, aa=aa, **kw)
+        assert rays == (scene.last_stats["rays_nearest"], scene.last_stats["rays_shadow"])
+        assert np.array_equal(bits(a), bits(b))
+    sc.close()
+
+
 def test_c5_full_size_from_a_mesh_file(tmp_path):
     # 4 999 122 triangles through the binary mesh ingest: 65 536 leaves of ~76 triangles (depth cap), which the packet
     # kernels read as long external runs, 16 at a time

@@ -600,10 +600,15 @@ __device__ __forceinline__ f3 phong(f3 I, const float* kd, const float* ks, floa
 	if (diffuse.y < 0) diffuse.y = 0;
 	if (diffuse.z < 0) diffuse.z = 0;
 	colour = colour + diffuse;
+	// A material without a specular colour (every wall of C4): I * ks is an exact zero per channel, and the power it would be multiplied
+	// with is finite for an exponent in [0, 1e6] (its base is at most 1 + a few ulp), so the term adds zero: R, its normalisation and
+	// powf are skipped.  A wave of the area-light kernel is one surface, so there the branch is uniform.
+	const f3 Iks = I * ld3(ks);
+	if (Iks.x == 0 && Iks.y == 0 && Iks.z == 0 && shininess >= 0.0f && shininess <= 1e6f) return colour;
 	f3 R = normalize(2 * (dot(N, L)) * N - L);
 	float RdotV = dot(R, V);
 	if (RdotV > 0) {
-		f3 specular = I * ld3(ks) * powf(RdotV, shininess);
+		f3 specular = Iks * powf(RdotV, shininess);
 		if (specular.x < 0) specular.x = 0;
 		if (specular.y < 0) specular.y = 0;
 		if (specular.z < 0) specular.z = 0;

@@ -59,7 +59,8 @@ class FlatScene:
         return np.array(self._h.contents.background[:], np.float32)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        # (at interpreter shutdown the module globals may already be gone: the process is about to release the memory anyway)
+        if getattr(self, "_h", None) and capi is not None and getattr(capi, "load", None) is not None:
             capi.load().rt_flat_scene_free(self._h)
             self._h = None
 
@@ -90,7 +91,9 @@ class Scene:
             capi.load().rt_scene_free(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        if capi is not None and getattr(capi, "load", None) is not None:   # (interpreter shutdown: see FlatScene.__del__)
+            self.close()
 
     def camera(self, width, height, eye=(0, 0, 0), rot_x=0.0, rot_y=0.0):
         return Camera(self.flat.fov, width, height, eye, rot_x, rot_y)

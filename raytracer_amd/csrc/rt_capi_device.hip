@@ -114,7 +114,7 @@ struct rt_scene {
 		hipStream_t stream = nullptr;    // owned, non-blocking (lane 0 also runs on the caller's stream)
 		RtTexRec* texRec = nullptr;      // texelFix only
 	};
-	RtTexFix texFix(const Lane& ln) const { return RtTexFix{ texelFix ? ln.texRec : nullptr, texHeads, texCap }; }
+	RtTexFix texFix(const Lane& ln) const { return RtTexFix{ texelFix ? ln.texRec : nullptr, texHeads, texCap, &ln.ctr->texrec_count }; }
 	uint32_t qcap = 0;
 	int maxBlocks = 2048;            // grid cap of the persistent kernels
 	int maxBlocksPacketNear = 2048;  // ... of the nearest-hit packet kernel (see rt_scene_upload)
@@ -779,15 +779,16 @@ struct Run {
 	// tree goes: it queues `ahead` levels beyond the last one whose counts it has read back, and stops when a level it reads
 	// turns out empty (the levels already queued behind that one find zero items and leave at once).  Bounds: a hit has at
 	// most one reflected and one transmitted child, so level L holds at most (children per hit)^k times the rays of level
-	// L - k, and never more than the queue does.  Not for counting / per-kernel timing runs, narration, or scenes that keep
-	// texel records (those read more than the counts after each level): they use levels().
+	// L - k, and never more than the queue does.  Not for counting / per-kernel timing runs or the narration
+	// (those read more than the counts after each level): they use levels().  Scenes that keep texel records do run ahead: the
+	// records' counter is one per batch (RtTexFix::count) and k_publish reports it with every level.
 	// Waits until k_publish has written the report queued with sequence number `seq`.  Spins for a while (the levels this loop is
 	// for take tens of microseconds), then sleeps between looks; a GPU error or ten seconds without the report end the wait.
 	int awaitReport(const RtLevelReport* slot, uint32_t seq, RtLevelReport& out) {
 		const auto t0 = std::chrono::steady_clock::now();
 		for (uint64_t spins = 0;; spins++) {
 			if (__atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) == seq) {
-				out.next_count = slot->next_count; out.surf_count = slot->surf_count; out.overflow = slot->overflow; out.seq = seq;
+				out.next_count = slot->next_count; out.surf_count = slot->surf_count; out.overflow = slot->overflow; out.texrec_count = slot->texrec_count; out.seq = seq;
 				return RT_OK;
 			}
 			if (spins < 4000) { __builtin_ia32_pause(); continue; }
@@ -802,7 +803,7 @@ struct Run {
 	}
 	bool canRunAhead() const {
 		static const bool off = getenv("RT_NO_LEVELS_AHEAD") != nullptr;
-		return !off && !(flags & (RT_FLAG_COUNTERS | RT_FLAG_TIME_KERNELS)) && !pick.ev && !sc->texelFix;
+		return !off && !(flags & (RT_FLAG_COUNTERS | RT_FLAG_TIME_KERNELS)) && !pick.ev;
 	}
 	int levelsAhead(uint32_t r0, uint32_t cnt) {
 		static const int ahead = (int)std::max<uint32_t>(1, std::min<uint32_t>(8, envU32("RT_LEVELS_AHEAD", 2)));
@@ -817,6 +818,7 @@ struct Run {
 		uint64_t known = cnt;              // rays of level `read` (exact)
 		uint64_t nearRays = 0, shadowRays = 0, nLevels = 0;
 		uint32_t seqOf[RT_MAX_LEVELS] = {};
+		texRecords = 0;
 		bool overflow = false;
 		int cur = 0;
 		for (;;) {
@@ -833,7 +835,7 @@ struct Run {
 				          shadows, lv == 0 ? src.outHit : nullptr, src.outId, src.outT, pick, sc->texFix(*ln), nDev);
 				if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, nb, ln->ray[cur ^ 1], &L[lv], sc->accum, aaSq, maxDepth, pick);
 				seqOf[lv] = ++ln->reportSeq ? ln->reportSeq : ++ln->reportSeq;   // (never 0)
-				rtk_publish(st, &L[lv], ln->reportDev + lv, seqOf[lv]);
+				rtk_publish(st, &L[lv], sc->texelFix ? &ln->ctr->texrec_count : nullptr, ln->reportDev + lv, seqOf[lv]);
 				if (shadows) {
 					if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nb, sc->pointLights, sc->nPointLights, sc->accum, aaSq, &L[lv], true, sc->maxBlocksPacketShadow2);
 					for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, false, ln->surfq, nb, al.first, al.second, seed, sc->accum, aaSq, &L[lv], true);
@@ -850,12 +852,22 @@ struct Run {
 			nLevels++;
 			shadowRays += (uint64_t)std::min<uint32_t>(c.surf_count, sc->qcap) * sc->shadowRaysPerSurface;
 			if (c.overflow) overflow = true;
+			texRecords = c.texrec_count;   // (records of every level up to this one: k_publish runs behind the level's shading)
 			known = overflow ? 0 : std::min<uint32_t>(c.next_count, sc->qcap);
 			read++;
 			if (read > lastLevel) known = 0;
 			if (known == 0) break;         // whatever is still queued behind this level finds no items and leaves at once
 		}
-		if (overflow) return 1;
+		if (overflow) {
+			// the levels still queued behind the one that overflowed may leave texel records too: batch() drops them by the count, so read it
+			if (sc->texelFix) {
+				HIPCHK(hipStreamSynchronize(st));
+				HIPCHK(hipMemcpy(&texRecords, &ln->ctr->texrec_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+			}
+			return 1;
+		}
+		// hits on reflective textured triangles that their own reflected ray's subtree came back to: lit with the last hit's texel
+		rtk_texel_fix(st, sc->dev, sc->hasCsg, sc->texFix(*ln), texRecords, ln->ctr, sc->accum, aaSq, seed, true);
 		stats.rays_nearest += nearRays; stats.rays_shadow += shadowRays; stats.levels = std::max<uint64_t>(stats.levels, nLevels);
 		return RT_OK;
 	}

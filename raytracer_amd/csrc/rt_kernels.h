@@ -110,7 +110,7 @@ struct RtCounters {
 };
 
 // what k_publish leaves in host memory for one level (Run::levelsAhead polls seq)
-struct RtLevelReport { uint32_t next_count, surf_count, overflow, seq; };
+struct RtLevelReport { uint32_t next_count, surf_count, overflow, texrec_count, seq; };   // texrec_count: RtTexFix records of the batch up to and including this level
 
 // Texel state of textured triangles (texturemesh.cpp:49-50, objects.cpp:62-79): TextureTriangle::lightPoint writes the texel into the
 // triangle's own material and Object::lightPoint reads it back only after it has traced the reflected ray, so a hit whose reflection
@@ -119,7 +119,7 @@ struct RtLevelReport { uint32_t next_count, surf_count, overflow, seq; };
 // k_texel_fix finds the records whose subtree holds a later hit on the same triangle and adds the difference of the ambient and
 // diffuse terms (shadow rays re-traced: such hits are rare).  Scenes without reflective textured triangles carry none of it.
 struct RtTexRec { uint32_t pixKey, path, tri, next; float c[3], wl[3], p[3], N[3]; };   // 64 B
-struct RtTexFix { RtTexRec* rec; uint32_t* heads; uint32_t cap; };                      // rec == nullptr: off.  heads: one list per pixel, kInactive = empty
+struct RtTexFix { RtTexRec* rec; uint32_t* heads; uint32_t cap; uint32_t* count; };    // rec == nullptr: off.  heads: one list per pixel, kInactive = empty.  count: records of the batch so far (all levels)
 
 // 32.32 fixed-point accumulators: three planes of npix, plus a per-pixel "saw a NaN/inf" byte
 struct RtAccum { unsigned long long* rgb; uint8_t* nonfinite; uint32_t npix; };
@@ -141,7 +141,7 @@ void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint3
                   RtPick pick = RtPick{ nullptr, nullptr, 0 });
 void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
                uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick = RtPick{ nullptr, nullptr, 0 },
-               RtTexFix tex = RtTexFix{ nullptr, nullptr, 0 }, const uint32_t* nDev = nullptr);
+               RtTexFix tex = RtTexFix{ nullptr, nullptr, 0, nullptr }, const uint32_t* nDev = nullptr);
 // after the last level of a batch: the corrections for `count` records, then the lists and the record counter are emptied again
 void rtk_texel_fix(hipStream_t st, const DevScene& S, bool csg, RtTexFix tex, uint32_t count, RtCounters* ctr, RtAccum A, uint32_t aaSq, uint32_t seed, bool apply);
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
@@ -152,4 +152,4 @@ void rtk_shadow_query(hipStream_t st, const DevScene& S, bool csg, const float* 
 void rtk_resolve(hipStream_t st, RtAccum A, int W, int H, int tileRank, int tileRanks, uint32_t lp0, uint32_t count, uint32_t aaSq, int linear, float* rgb);
 void rtk_tiles_copy(hipStream_t st, const float* src, float* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode);
 void rtk_tiles_rgb8(hipStream_t st, const void* src, uint8_t* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode);
-void rtk_publish(hipStream_t st, const RtCounters* ctr, RtLevelReport* hostMapped, uint32_t seq);
+void rtk_publish(hipStream_t st, const RtCounters* ctr, const uint32_t* texCount, RtLevelReport* hostMapped, uint32_t seq);

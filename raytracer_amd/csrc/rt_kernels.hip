@@ -1392,7 +1392,7 @@ __global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX || MULTI) ? 1 : 8) v
 		} else ctr->overflow = 1;
 	}
 	if (TEXFIX) {
-		const uint32_t slot = wavePush(wantTex, &ctr->texrec_count);
+		const uint32_t slot = wavePush(wantTex, tex.count);
 		if (wantTex) {
 			if (slot < tex.cap) {
 				RtTexRec r;
@@ -1894,7 +1894,7 @@ __global__ __launch_bounds__(kBlock) void k_texel_fix(DevScene S, RtTexFix tex, 
 // empties the lists the records hang in and the record counter: the next batch starts clean
 __global__ __launch_bounds__(kBlock) void k_texel_reset(RtTexFix tex, uint32_t count, RtCounters* ctr, uint32_t aaSq) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	if (i == 0) ctr->texrec_count = 0;
+	if (i == 0) *tex.count = 0;
 	if (i < count) tex.heads[tex.rec[i].pixKey / aaSq] = kInactive;
 }
 
@@ -1964,8 +1964,9 @@ __global__ __launch_bounds__(kBlock) void k_tiles_rgb8(const void* src, uint8_t*
 // The counts of a level, written straight into host memory (pinned, mapped) for the host loop that runs ahead of the GPU: one
 // 64-thread launch instead of a copy and an event in the stream, and the host sees them as soon as the store lands instead of
 // after a copy engine and an interrupt.  `seq` (never 0) goes last, behind a system-scope fence: the host polls it.
-__global__ __launch_bounds__(64) void k_publish(const RtCounters* ctr, RtLevelReport* host, uint32_t seq) {
+__global__ __launch_bounds__(64) void k_publish(const RtCounters* ctr, const uint32_t* texCount, RtLevelReport* host, uint32_t seq) {
 	if (threadIdx.x != 0) return;
+	host->texrec_count = texCount ? *texCount : 0u;
 	host->next_count = ctr->next_count;
 	host->surf_count = ctr->surf_count;
 	host->overflow = ctr->overflow;
@@ -2151,6 +2152,6 @@ void rtk_tiles_copy(hipStream_t st, const float* src, float* dst, int W, int H, 
 void rtk_tiles_rgb8(hipStream_t st, const void* src, uint8_t* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode) {
 	RT_LAUNCH(k_tiles_rgb8, count, st, src, dst, W, H, tileRank, tileRanks, count, mode);
 }
-void rtk_publish(hipStream_t st, const RtCounters* ctr, RtLevelReport* hostMapped, uint32_t seq) {
-	RT_LAUNCH_RAW(k_publish, dim3(1), dim3(64), 0, st, ctr, hostMapped, seq);
+void rtk_publish(hipStream_t st, const RtCounters* ctr, const uint32_t* texCount, RtLevelReport* hostMapped, uint32_t seq) {
+	RT_LAUNCH_RAW(k_publish, dim3(1), dim3(64), 0, st, ctr, texCount, hostMapped, seq);
 }

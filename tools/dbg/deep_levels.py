@@ -11,8 +11,10 @@ with tempfile.TemporaryDirectory() as tmp:
     with open(scenes.c2_scene(tmp, grid=224)) as f:
         doc = json.load(f)
     mesh, s1, s2 = doc["objects"][:3]
-    mesh["type"] = "mesh"; mesh.pop("texture"); mesh.pop("uvCoords")
-    mesh["material"]["diffuse"] = [0.5, 0.6, 0.4]; mesh["material"]["reflective"] = [0.4, 0.4, 0.4]
+    if os.environ.get("TEXTURED") != "1":   # (TEXTURED=1: the field stays a texturemesh, so its hits leave texel records)
+        mesh["type"] = "mesh"; mesh.pop("texture"); mesh.pop("uvCoords")
+        mesh["material"]["diffuse"] = [0.5, 0.6, 0.4]
+    mesh["material"]["reflective"] = [0.4, 0.4, 0.4]
     for sph in (s1, s2):
         sph["type"] = "sphere"; sph.pop("bumpmap"); sph.pop("bumpdepth")
     s1["material"]["reflective"] = [0.5, 0.5, 0.5]
@@ -22,7 +24,7 @@ with tempfile.TemporaryDirectory() as tmp:
         json.dump(doc, f)
     flat = rt.FlatScene.from_json(path)
     sc = rt.Scene(flat, 0)
-    W, H = 1920, 1080
+    W, H = (int(v) for v in os.environ.get("SIZE", "1920x1080").split("x"))
     cam = rt.Camera(flat.fov, W, H, eye=(0, 1.5, 1.0), rot_x=-0.3)
     frame = torch.zeros(H, W, 3, device="cuda")
     for levels in ("8", "1", "2", "0"):

@@ -1720,7 +1720,8 @@ __device__ __forceinline__ float waveSumToLane63(float v) {
 // Rectangular / circular area light `lightIndex`: one lane per (surface, sample), samples of one surface in
 // consecutive lanes (their rays leave the same point towards neighbouring targets), summed across lanes by a
 // segmented shuffle scan so each surface costs one atomic per wave instead of one per sample.
-template <bool CSG, bool COUNT>
+// WHOLE: the number of samples is a multiple of 64, so every wave is one surface
+template <bool CSG, bool COUNT, bool WHOLE>
 __global__ __launch_bounds__(kBlock, RT_AREA_WAVES_PER_SIMD) void k_shadow_area(DevScene S, RtQueue sq, uint32_t nsurfArg, int lightIndex, uint32_t seed,
                                                         RtAccum A, uint32_t aaSq, RtCounters* ctr, int countOnDevice) {
 	const uint32_t nsurf = countOnDevice ? deviceCount(nsurfArg, &ctr->surf_count) : nsurfArg;
@@ -1756,35 +1757,55 @@ __global__ __launch_bounds__(kBlock, RT_AREA_WAVES_PER_SIMD) void k_shadow_area(
 		travInit<true>(S, T, p, lightPos - p);
 	}
 	packetTraverse<true, CSG, COUNT>(S, ws, T, live);
-	f3 w = mk3(0, 0, 0);
-	uint32_t pixKey = 0;
-	if (live) {
-		if (COUNT) { atomicAdd(&ctr->nodes_shadow, T.cntNodes); atomicAdd(&ctr->prims_shadow, T.cntPrims); if ((threadIdx.x & 63) == 0) atomicAdd(&ctr->steps_shadow, (unsigned long long)T.cntSteps); }
-		if (T.lit) {
-			const Surface sf = loadSurface(sq, s);
-			c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
-		}
-	}
 	const uint32_t lane = __lane_id();
-	uint32_t nextKey = s;
-	if ((ns & 63u) == 0u) {
-		// a multiple of 64 samples: the wave is one surface and lane 63 gets the sum through the DPP network instead of 24 LDS
-		// permutes -- the same balanced tree of additions over the lanes in order as the scan below, so the same bits
-		c.x = waveSumToLane63(c.x); c.y = waveSumToLane63(c.y); c.z = waveSumToLane63(c.z);
-	} else {
-		// segmented inclusive scan over the wave, key = surface
-#pragma unroll
-		for (int off = 1; off < 64; off <<= 1) {
-			const uint32_t ks2 = __shfl_up(s, off);
-			const float ax = __shfl_up(c.x, off), ay = __shfl_up(c.y, off), az = __shfl_up(c.z, off);
-			if (lane >= (uint32_t)off && ks2 == s) { c.x += ax; c.y += ay; c.z += az; }
+	if constexpr (WHOLE) {
+		f3 w = mk3(0, 0, 0);
+		uint32_t pixKey = 0;
+		if (live) {
+			if (COUNT) { atomicAdd(&ctr->nodes_shadow, T.cntNodes); atomicAdd(&ctr->prims_shadow, T.cntPrims); if ((threadIdx.x & 63) == 0) atomicAdd(&ctr->steps_shadow, (unsigned long long)T.cntSteps); }
+			if (T.lit) {
+				const Surface sf = loadSurface(sq, s);
+				c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
+			}
 		}
-		nextKey = __shfl_down(s, 1);
-	}
-	if (live && (lane == 63u || nextKey != s)) {   // arealight.cpp:21
-		w = mk3(qf(sq, SQ_WR, s), qf(sq, SQ_WG, s), qf(sq, SQ_WB, s));
-		pixKey = qu(sq, SQ_PIX, s);
-		accumAdd(A, pixKey / aaSq, w * (c / (float)ns));
+		uint32_t nextKey = s;
+		if ((ns & 63u) == 0u) {
+			// a multiple of 64 samples: the wave is one surface and lane 63 gets the sum through the DPP network instead of 24 LDS
+			// permutes -- the same balanced tree of additions over the lanes in order as a scan would build
+			c.x = waveSumToLane63(c.x); c.y = waveSumToLane63(c.y); c.z = waveSumToLane63(c.z);
+		} else {
+			// (never taken: rtk_shadow_area sends other sample counts to the variant below.  Kept because the register allocation of this
+			// kernel, which runs at its 128-VGPR limit with spills, came out 10 % slower on C4 without it)
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) {
+				const uint32_t ks2 = __shfl_up(s, off);
+				const float ax = __shfl_up(c.x, off), ay = __shfl_up(c.y, off), az = __shfl_up(c.z, off);
+				if (lane >= (uint32_t)off && ks2 == s) { c.x += ax; c.y += ay; c.z += az; }
+			}
+			nextKey = __shfl_down(s, 1);
+		}
+		if (live && (lane == 63u || nextKey != s)) {   // arealight.cpp:21
+			w = mk3(qf(sq, SQ_WR, s), qf(sq, SQ_WG, s), qf(sq, SQ_WB, s));
+			pixKey = qu(sq, SQ_PIX, s);
+			accumAdd(A, pixKey / aaSq, w * (c / (float)ns));
+		}
+	} else {
+		// Any other number of samples: a surface's samples straddle waves, and WHERE depends on the surface's slot in the queue, which
+		// is whatever order the shading kernel's workgroups reached the append counter in -- float partial sums per wave would make the
+		// last bit of a pixel differ from run to run.  Each sample's share goes to fixed point by itself instead and the lanes of a
+		// pixel add up as integers (accumAddRows): the same bits whatever the order.
+		f3 w = mk3(0, 0, 0);
+		uint32_t pixKey = 0;
+		bool lit = false;
+		if (live) {
+			if (COUNT) { atomicAdd(&ctr->nodes_shadow, T.cntNodes); atomicAdd(&ctr->prims_shadow, T.cntPrims); if ((threadIdx.x & 63) == 0) atomicAdd(&ctr->steps_shadow, (unsigned long long)T.cntSteps); }
+			if (T.lit) {
+				const Surface sf = loadSurface(sq, s);
+				c = phong(ld3(L.colour) * T.shadow, sf.kd, sf.ks, sf.shininess, sf.N, normalize(lightPos - sf.p), sf.V);   // arealight.cpp:13-19
+				w = sf.w; pixKey = sf.pixKey; lit = true;
+			}
+		}
+		accumAddRows(A, lit ? pixKey / aaSq : 0xffffffffu - lane, w * (c / (float)ns), lit, mk3(0, 0, 0), false);
 	}
 }
 
@@ -2136,8 +2157,15 @@ void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, bool count, Rt
                      RtAccum A, uint32_t aaSq, RtCounters* ctr, bool countOnDevice) {
 	const int cod = countOnDevice ? 1 : 0;
 	const unsigned long long items = (unsigned long long)nsurf * samples;
-	if (csg) { if (count) RT_LAUNCH_S((k_shadow_area<true, true>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr, cod); else RT_LAUNCH_S((k_shadow_area<true, false>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr, cod); }
-	else { if (count) RT_LAUNCH_S((k_shadow_area<false, true>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr, cod); else RT_LAUNCH_S((k_shadow_area<false, false>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr, cod); }
+#define RT_AREA(...) RT_LAUNCH_S((k_shadow_area<__VA_ARGS__>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr, cod)
+	if (samples % 64u == 0u) {   // every wave is one surface
+		if (csg) { if (count) RT_AREA(true, true, true); else RT_AREA(true, false, true); }
+		else { if (count) RT_AREA(false, true, true); else RT_AREA(false, false, true); }
+	} else {
+		if (csg) { if (count) RT_AREA(true, true, false); else RT_AREA(true, false, false); }
+		else { if (count) RT_AREA(false, true, false); else RT_AREA(false, false, false); }
+	}
+#undef RT_AREA
 }
 void rtk_shadow_query(hipStream_t st, const DevScene& S, bool csg, const float* point, const float* lightPos, uint32_t n, uint8_t* lit, float* shadow) {
 	if (csg) RT_LAUNCH((k_shadow_query<true>), n, st, S, point, lightPos, n, lit, shadow);

@@ -637,6 +637,11 @@ def test_texel_state_with_many_records(tmp_path, monkeypatch, queue_rays, W, H, 
     img = sc.render(W, H, aa=aa, camera=cam, max_depth=depth, seed=9)
     splits = sc.last_stats["batch_splits"]
     nn, ns = sc.last_stats["rays_nearest"], sc.last_stats["rays_shadow"]
+    # the frame above went through the level loop that runs ahead of the host (the records' count comes with k_publish's reports);
+    # with per-kernel timing asked for, the loop that reads the counters back after every level runs: the same frame, bit for bit
+    timed = sc.render(W, H, aa=aa, camera=cam, max_depth=depth, seed=9, flags=2)
+    assert (sc.last_stats["rays_nearest"], sc.last_stats["rays_shadow"]) == (nn, ns)
+    assert np.array_equal(bits(img), bits(timed))
     sc.close()
     oracle.texel_cases()
     ref, onn, ons = oracle.render(flat, cam, W, H, aa=aa, max_depth=depth, seed=9, threads=8)

@@ -190,6 +190,32 @@ def test_render_is_deterministic_and_tiles_compose(gpu_scenes, flat_scenes):
     assert np.array_equal(bits(full.cpu().numpy()), bits(a))
 
 
+def test_area_light_frames_are_deterministic_whatever_the_queue_order(flat_scenes, monkeypatch):
+    """Scene m (one area light, 100 samples: a surface's samples straddle waves, and where depends on the order in which the shading
+    kernel's workgroups appended their surfaces): per-sample fixed-point shares added as integers, so the frame is the same bit for
+    bit run to run, on one lane or four, for the whole frame or three ranks' tiles, and through the level loop that reads its
+    counters back (flags = 2: per-kernel timing)."""
+    import torch
+    import raytracer_amd as rt
+    fs = flat_scenes("m")
+    W, H = 200, 100
+    cam = rt.Camera(fs.fov, W, H)
+    sc = rt.Scene(fs, 0)
+    a = sc.render(W, H, camera=cam, seed=5)
+    for _ in range(3):
+        assert np.array_equal(bits(a), bits(sc.render(W, H, camera=cam, seed=5)))
+    assert np.array_equal(bits(a), bits(sc.render(W, H, camera=cam, seed=5, flags=2)))
+    full = torch.zeros(H, W, 3, device="cuda")
+    for rank in range(3):
+        sc.render_into(full.data_ptr(), W, H, camera=cam, seed=5, tile_rank=rank, tile_ranks=3)
+    assert np.array_equal(bits(full.cpu().numpy()), bits(a))
+    sc.close()
+    monkeypatch.setenv("RT_LANES", "1")
+    one = rt.Scene(fs, 0)
+    assert np.array_equal(bits(a), bits(one.render(W, H, camera=cam, seed=5)))
+    one.close()
+
+
 def test_tiles_exchange_with_8_bit_pixels_equals_host_quantiser(gpu_scenes, flat_scenes):
     """The exchange with 8-bit pixels (rt_tiles_pack_rgb8 / _unpack_rgb8 / _quantize_rgb8): the frame assembled from three ranks'
     byte payloads is, byte for byte, rt_quantize_rgb8 of the single-rank float frame -- NaN, negative and > 1 pixels included."""

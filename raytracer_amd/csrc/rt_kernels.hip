@@ -2086,7 +2086,9 @@ void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue 
 		return;
 	}
 #define RT_SHADE(...) RT_LAUNCH((k_shade<__VA_ARGS__>), n, st, S, rq, hq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, wantSurfaces, outHit, outId, outT, pick, tex)
-	const bool multi = aaSq > 1 && getenv("RT_NO_ROW_SUMS") == nullptr;   // several samples per pixel: the variants that combine their accumulator atomics (the switch: for the tests, read per call)
+	// several samples per pixel: the variants that combine their accumulator atomics (the switch: for the tests, read per call).  From three
+	// samples on: measured on C2 at 1080p with 2 / 4 / 8 samples per pixel (tools/dbg/aa_times.py), the row sums cost 3 % / gain 37 % / 56 %
+	const bool multi = aaSq > 2 && getenv("RT_NO_ROW_SUMS") == nullptr;
 	if (tex.rec) {   // scenes with reflective textured triangles
 		if (csg) { if (multi) RT_SHADE(true, false, true, true); else RT_SHADE(true, false, true, false); }
 		else { if (multi) RT_SHADE(false, false, true, true); else RT_SHADE(false, false, true, false); }
@@ -2134,7 +2136,7 @@ void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, b
 			else { if (count) RT_LAUNCH_PS((k_shadow_point_packet<false, true>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); else RT_LAUNCH_PS((k_shadow_point_packet<false, false>), oitems, maxBlocks, packetLdsBytes(S), st, S, sq, nsurf, last, 1u, A, aaSq, ctr, cod, 1); }
 		}
 #define RT_PAIRS(...) RT_LAUNCH_PS((k_shadow_point_packet2<__VA_ARGS__>), pitems, maxBlocksPairs > 0 ? maxBlocksPairs : maxBlocks, packetLdsBytes(S) + (RT_BLOCK / 64) * RT_PACKET_COLD_BYTES, st, S, sq, nsurf, lightList, nPairs, A, aaSq, ctr, cod)
-		if (aaSq > 1 && getenv("RT_NO_ROW_SUMS") == nullptr) {   // several samples per pixel: the variants that combine their accumulator atomics (accumAddRows)
+		if (aaSq > 2 && getenv("RT_NO_ROW_SUMS") == nullptr) {   // several samples per pixel: the variants that combine their accumulator atomics (accumAddRows)
 			if (csg) { if (count) RT_PAIRS(true, true, true); else RT_PAIRS(true, false, true); }
 			else { if (count) RT_PAIRS(false, true, true); else RT_PAIRS(false, false, true); }
 		} else {

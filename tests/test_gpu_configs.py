@@ -471,7 +471,7 @@ def test_deeper_levels_in_packets(tmp_path, monkeypatch, textured):
     sc.close()
 
 
-@pytest.mark.parametrize("aa", [(2, 1), (2, 2), (4, 4), (3, 5)])
+@pytest.mark.parametrize("aa", [(3, 1), (2, 2), (4, 4), (3, 5)])
 def test_row_sums_of_multi_sample_frames_are_exact(tmp_path, monkeypatch, gpu_scenes, aa):
     """Frames with several samples per pixel add the fixed-point contributions of neighbouring lanes before the accumulator atomics
     (accumAddRows: the shading kernel and the two-light shadow kernel).  Integer sums, so the frame must equal, bit for bit, the one

@@ -82,6 +82,7 @@ struct rt_scene {
 	StaticScratch* staticScratch = nullptr;   // this device's copy of `scratch` (rt_intersect_batch_static)
 	DevScene dev{};
 	bool hasCsg = false;
+	int nCsg = 0;                   // CSG objects in the scene (rtk_shadow_area: few enough to defer their evaluation)
 	bool hasTransmissive = false;   // some material transmits: k_shade queues requests for k_transmit
 	bool hasReflective = false;     // some material reflects (with hasTransmissive: how many children a hit can have)
 	// some textured triangle reflects: its hits leave records for k_texel_fix (RtTexFix in rt_kernels.h).  The per-pixel list heads
@@ -754,7 +755,7 @@ struct Run {
 			else if (nsurf > 0 && sc->shadowRaysPerSurface > 0) {
 				if (timeK) HIPCHK(hipEventRecord(ln->ev[4], st));
 				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, coherent(level), coherent(level) ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nsurf, sc->pointLights, sc->nPointLights, sc->accum, aaSq, ln->ctr, false, sc->maxBlocksPacketShadow2);
-				for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, count, ln->surfq, nsurf, al.first, al.second, seed, sc->accum, aaSq, ln->ctr);
+				for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, sc->nCsg, count, ln->surfq, nsurf, al.first, al.second, seed, sc->accum, aaSq, ln->ctr);
 				if (timeK) { HIPCHK(hipEventRecord(ln->ev[5], st)); shadowPending = true; }
 				shadowRays += (uint64_t)nsurf * sc->shadowRaysPerSurface;
 			}
@@ -838,7 +839,7 @@ struct Run {
 				rtk_publish(st, &L[lv], sc->texelFix ? &ln->ctr->texrec_count : nullptr, ln->reportDev + lv, seqOf[lv]);
 				if (shadows) {
 					if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nb, sc->pointLights, sc->nPointLights, sc->accum, aaSq, &L[lv], true, sc->maxBlocksPacketShadow2);
-					for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, false, ln->surfq, nb, al.first, al.second, seed, sc->accum, aaSq, &L[lv], true);
+					for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, sc->nCsg, false, ln->surfq, nb, al.first, al.second, seed, sc->accum, aaSq, &L[lv], true);
 				}
 				if (int rcL = launchesOk()) return rcL;
 				cur ^= 1;
@@ -1144,6 +1145,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	memcpy(D.root_box, s->root_box, sizeof D.root_box);
 	memcpy(D.background, s->background, sizeof D.background);
 	sc->hasCsg = s->n_csgs > 0;
+	sc->nCsg = s->n_csgs;
 	D.csg_cap = csgCapacity(s);
 	D.csg_nodes_max = 1;
 	for (int32_t i = 0; i < s->n_csgs; i++) D.csg_nodes_max = std::max(D.csg_nodes_max, s->csgs[i].node_count);

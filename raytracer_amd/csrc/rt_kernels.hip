@@ -679,19 +679,27 @@ __device__ __forceinline__ void quadClassify(const float4* q, const Trav& T, f3 
 }
 
 // `alive`: the lane holds a query.  T must come from travInit (T.cur == kEmpty: the lane's ray missed the root box).
-template <bool ANYHIT, bool CSG, bool COUNT>
+// DEFER (shadow queries of scenes with at most RT_PACKET_STACK_DEPTH CSG objects): a CSG leaf is not evaluated where the walk meets it.
+// The walk notes the object and the lanes whose rays reached it in the unused half of a stack slot (a leaf is met once per packet, so
+// one slot per object is enough) and the objects are evaluated when the walk is over.  The evaluation's registers then do not overlap
+// the walk's: with csgEval inside the loop the area-light kernel spilled in its node steps and C4 paid 1.3 of its 9.4 ms for having
+// CSG objects at all, whether a ray came near them or not.  Any order is correct for a shadow query.
+template <bool ANYHIT, bool CSG, bool COUNT, bool DEFER = false>
 __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLds& L, Trav& T, bool alive, Tracer* trp = nullptr) {
+	static_assert(!DEFER || (ANYHIT && CSG), "deferred CSG leaves: shadow queries only");
 	const uint32_t lane = __lane_id();
 	bool inSub = alive && T.cur != kEmpty;   // this lane's ray passed the box of the current node
 	if (__ballot(inSub) == 0) return;
 	int32_t node = S.treelet_root;
 	uint32_t info = node < 0 ? S.treelet_root_aux : 0u;   // inner node: treelet level; leaf: aux
 	int sp = 0;
+	int nDeferred = 0;
+	bool walking = true;
 	// (Measured and dropped: raising the wave's issue priority with the length of its walk, and prefetching a pushed
 	// treelet with an asynchronous global->LDS copy into a scratch buffer -- neither moved the launch time: the long
 	// walks that end a launch are bound by their own chain of dependent steps.  Their tails are instead filled with
 	// other shards of the frame, see rt_capi_device.hip.)
-	for (;;) {
+	while (walking) {
 		node = __builtin_amdgcn_readfirstlane(node);
 		info = __builtin_amdgcn_readfirstlane(info);
 		bool popNext = true;
@@ -768,14 +776,20 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			int32_t at = ~node;
 			for (;;) {
 				const uint32_t entry = *(cuint32*)(uintptr_t)(S.leaf_prims + at);
-				packetPrim<ANYHIT, CSG, COUNT>(S, T, inSub, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u);
+				if (DEFER && RT_PRIM_TYPE(entry & ~RT_PRIM_LAST) == RT_PRIM_CSG) {   // (wave-uniform)
+					const unsigned long long m = __ballot(inSub && T.lit);
+					if (m != 0 && nDeferred < RT_PACKET_STACK_DEPTH) {
+						if (lane == 0) reinterpret_cast<uint4*>(L.stack[nDeferred])[1] = make_uint4(entry & ~RT_PRIM_LAST, (uint32_t)m, (uint32_t)(m >> 32), (uint32_t)at + 1u);
+						nDeferred++;
+					}
+				} else packetPrim<ANYHIT, CSG && !DEFER, COUNT>(S, T, inSub, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u);
 				if (entry & RT_PRIM_LAST) break;
 				at++;
 			}
 		}
 		if (popNext) {
 			for (;;) {
-				if (sp == 0) return;
+				if (sp == 0) { walking = false; break; }
 				sp--;
 				const uint4 entry = *reinterpret_cast<const uint4*>(L.stack[sp]);
 				const unsigned long long m = (unsigned long long)entry.y | ((unsigned long long)entry.z << 32);
@@ -784,6 +798,17 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 				inSub = ((m >> lane) & 1ull) != 0 && (!ANYHIT || T.lit);
 				if (__ballot(inSub) != 0) break;   // nobody left who wants this subtree (occluded lanes)
 			}
+		}
+	}
+	if (DEFER) {
+		for (int i = 0; i < nDeferred; i++) {
+			const uint4 en = reinterpret_cast<const uint4*>(L.stack[i])[1];
+			const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.x);
+			const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)en.y) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)en.z) << 32);
+			const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.w);
+			const bool in = ((m >> lane) & 1ull) != 0 && T.lit;
+			if (__ballot(in) == 0) continue;
+			packetPrim<ANYHIT, CSG, COUNT>(S, T, in, ref, key);
 		}
 	}
 }
@@ -1720,8 +1745,8 @@ __device__ __forceinline__ float waveSumToLane63(float v) {
 // Rectangular / circular area light `lightIndex`: one lane per (surface, sample), samples of one surface in
 // consecutive lanes (their rays leave the same point towards neighbouring targets), summed across lanes by a
 // segmented shuffle scan so each surface costs one atomic per wave instead of one per sample.
-// WHOLE: the number of samples is a multiple of 64, so every wave is one surface
-template <bool CSG, bool COUNT, bool WHOLE>
+// WHOLE: the number of samples is a multiple of 64, so every wave is one surface.  DEFER: see packetTraverse
+template <bool CSG, bool COUNT, bool WHOLE, bool DEFER>
 __global__ __launch_bounds__(kBlock, RT_AREA_WAVES_PER_SIMD) void k_shadow_area(DevScene S, RtQueue sq, uint32_t nsurfArg, int lightIndex, uint32_t seed,
                                                         RtAccum A, uint32_t aaSq, RtCounters* ctr, int countOnDevice) {
 	const uint32_t nsurf = countOnDevice ? deviceCount(nsurfArg, &ctr->surf_count) : nsurfArg;
@@ -1756,7 +1781,7 @@ __global__ __launch_bounds__(kBlock, RT_AREA_WAVES_PER_SIMD) void k_shadow_area(
 		lightPos = ld3(L.position) + ld3(L.planeX) * xDisplacement + ld3(L.planeY) * yDisplacement;
 		travInit<true>(S, T, p, lightPos - p);
 	}
-	packetTraverse<true, CSG, COUNT>(S, ws, T, live);
+	packetTraverse<true, CSG, COUNT, DEFER>(S, ws, T, live);
 	const uint32_t lane = __lane_id();
 	if constexpr (WHOLE) {
 		f3 w = mk3(0, 0, 0);
@@ -2155,17 +2180,20 @@ void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, b
 	if (csg) { if (count) RT_LAUNCH_P((k_shadow_point<true, true>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); else RT_LAUNCH_P((k_shadow_point<true, false>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); }
 	else { if (count) RT_LAUNCH_P((k_shadow_point<false, true>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); else RT_LAUNCH_P((k_shadow_point<false, false>), items, maxBlocks, st, S, sq, nsurf, lightList, nLights, A, aaSq, ctr, cod); }
 }
-void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, bool count, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t samples, uint32_t seed,
+void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, int nCsg, bool count, RtQueue sq, uint32_t nsurf, int lightIndex, uint32_t samples, uint32_t seed,
                      RtAccum A, uint32_t aaSq, RtCounters* ctr, bool countOnDevice) {
 	const int cod = countOnDevice ? 1 : 0;
 	const unsigned long long items = (unsigned long long)nsurf * samples;
 #define RT_AREA(...) RT_LAUNCH_S((k_shadow_area<__VA_ARGS__>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr, cod)
+	const bool defer = csg && nCsg <= RT_PACKET_STACK_DEPTH && getenv("RT_NO_CSG_DEFER") == nullptr;   // (the switch: for the tests, read per call)
 	if (samples % 64u == 0u) {   // every wave is one surface
-		if (csg) { if (count) RT_AREA(true, true, true); else RT_AREA(true, false, true); }
-		else { if (count) RT_AREA(false, true, true); else RT_AREA(false, false, true); }
+		if (defer) { if (count) RT_AREA(true, true, true, true); else RT_AREA(true, false, true, true); }
+		else if (csg) { if (count) RT_AREA(true, true, true, false); else RT_AREA(true, false, true, false); }
+		else { if (count) RT_AREA(false, true, true, false); else RT_AREA(false, false, true, false); }
 	} else {
-		if (csg) { if (count) RT_AREA(true, true, false); else RT_AREA(true, false, false); }
-		else { if (count) RT_AREA(false, true, false); else RT_AREA(false, false, false); }
+		if (defer) { if (count) RT_AREA(true, true, false, true); else RT_AREA(true, false, false, true); }
+		else if (csg) { if (count) RT_AREA(true, true, false, false); else RT_AREA(true, false, false, false); }
+		else { if (count) RT_AREA(false, true, false, false); else RT_AREA(false, false, false, false); }
 	}
 #undef RT_AREA
 }

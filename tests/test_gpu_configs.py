@@ -492,6 +492,25 @@ def test_row_sums_of_multi_sample_frames_are_exact(tmp_path, monkeypatch, gpu_sc
     sc.close()
 
 
+@pytest.mark.parametrize("samples", [64, 24])
+def test_deferred_csg_leaves_of_area_light_shadow_rays(tmp_path, monkeypatch, samples):
+    """The area-light kernel notes the CSG objects its shadow rays reach and evaluates them when the walk is over (scenes with at most
+    48 CSG objects; packetTraverse, DEFER).  The C4 room (two CSG objects) with 64 samples per light -- a wave is one surface -- and with
+    24: the frame against the one with csgEval inside the walk (RT_NO_CSG_DEFER), bit for bit, and against the oracle's ray counts."""
+    flat = rt.FlatScene.from_json(scenes.c4_scene(str(tmp_path), samples))
+    sc = rt.Scene(flat, 0)
+    W, H = 320, 180
+    a = sc.render(W, H, seed=3)
+    rays = (sc.last_stats["rays_nearest"], sc.last_stats["rays_shadow"])
+    monkeypatch.setenv("RT_NO_CSG_DEFER", "1")
+    b = sc.render(W, H, seed=3)
+    assert rays == (sc.last_stats["rays_nearest"], sc.last_stats["rays_shadow"])
+    assert np.array_equal(bits(a), bits(b))
+    _, nn, ns = oracle.render(flat, rt.Camera(flat.fov, W, H), W, H, seed=3, threads=8)
+    assert rays == (nn, ns)
+    sc.close()
+
+
 def test_c5_full_size_from_a_mesh_file(tmp_path):
     # 4 999 122 triangles through the binary mesh ingest: 65 536 leaves of ~76 triangles (depth cap), which the packet
     # kernels read as long external runs, 16 at a time

@@ -52,6 +52,9 @@ typedef struct rt_stats {
 	float    max_walk;         /* longest nearest-hit walk of the call in nodes (only when RT_FLAG_COUNTERS) */
 	uint64_t steps_nearest;    /* node steps of the PACKET walks (one per wave and node visited, x 64 rays): nodes / (64 * steps) is the */
 	uint64_t steps_shadow;     /* fraction of a packet's lanes whose own ray is in the node (only when RT_FLAG_COUNTERS)              */
+	uint64_t state_cases;      /* exit searches of transmitted rays that found no exit (objects.cpp:123-125): the reference goes on from its */
+	                           /* objects' hit caches there -- for top-level meshes state left by EARLIER pixels, which the device does not   */
+	                           /* have.  An upper bound on the rays (pixels) that may differ from the reference for that reason; always filled */
 } rt_stats;
 
 #define RT_FLAG_COUNTERS   1u   /* count nodes / primitive tests in the traversal kernels (slower) */
@@ -172,7 +175,12 @@ int rt_intersect_batch(rt_scene* scene, const float* e, const float* d, size_t n
  *   - the work is enqueued on `stream` and NOT waited for: results are there once `stream` has reached this point.
  * Every call on one GPU -- whatever the rt_scene handle -- shares that GPU's array: calls that overlap in time on one GPU
  * (two streams, two threads) race.  Calls one after the other on one stream are fine; the array keeps the previous call's
- * contents and the call clears what must start at zero. */
+ * contents and the call clears what must start at zero.
+ * Under stream capture (hipStreamBeginCapture on `stream`): the call records one memset and three kernel launches and does
+ * nothing else -- which needs (1) no frame of this handle in flight or un-waited-for (outside capture the call waits for them
+ * on the host; a capturing stream cannot), and (2) one earlier, un-captured call on the same handle (the first call loads the
+ * kernels and asks for their occupancy).  Either condition missing: RT_EINVAL, nothing recorded.  Replays of the graph follow the
+ * same rule as calls: one at a time per GPU. */
 #define RT_STATIC_MAX_RAYS 65536u
 int rt_intersect_batch_static(rt_scene* scene, const float* e_dev, const float* d_dev, size_t n,
                               uint8_t* hit_dev, int32_t* obj_id_dev, float* t_dev, void* stream);
@@ -209,7 +217,8 @@ int rt_tiles_quantize_rgb8(rt_scene* scene, const float* frame_dev, uint8_t* fra
  * camera basis of the frame last displayed (which is what the movement keys move along, as in the reference).
  *   rt_view_key       keyboard() q1.cpp:179-247: w s a d (move), q e r f (turn, r / f limited to +-pi/2), t g (up / down), l (4x
  *                     supersampling on / off), p (prints camera and facing), space, Escape.  Returns 1 if the key starts a new frame
- *                     (drawing_y = 0), 0 if not, -1 for Escape (the reference exits); what the reference prints goes to `text`.
+ *                     (drawing_y = 0), 0 if not, -1 for Escape (the reference exits), -2 for a NULL view (rt_last_error says so); what the
+ *                     reference prints goes to `text`.
  *   rt_view_reshape   reshape() q1.cpp:278-288
  *   rt_view_render    display() q1.cpp:107-175 as ONE frame on the GPU: setFacing(), then every pixel (4 s_aa samples with `l` on);
  *                     rgb_dev as in rt_render

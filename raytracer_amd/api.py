@@ -212,7 +212,9 @@ class View:
             capi.load().rt_view_free(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        if capi is not None and getattr(capi, "load", None) is not None:   # (interpreter shutdown: see FlatScene.__del__)
+            self.close()
 
     def key(self, key):
         """keyboard(key): returns (result, text) -- 1 new frame, 0 none, -1 Escape; text = what the reference prints."""

@@ -44,7 +44,8 @@ class rt_stats(C.Structure):
     _fields_ = [("rays_nearest", C.c_uint64), ("rays_shadow", C.c_uint64), ("nodes_nearest", C.c_uint64), ("prims_nearest", C.c_uint64),
                 ("nodes_shadow", C.c_uint64), ("prims_shadow", C.c_uint64),
                 ("levels", C.c_uint64), ("batch_splits", C.c_uint64), ("gpu_ms", C.c_float), ("nearest_ms", C.c_float),
-                ("shadow_ms", C.c_float), ("max_walk", C.c_float), ("steps_nearest", C.c_uint64), ("steps_shadow", C.c_uint64)]
+                ("shadow_ms", C.c_float), ("max_walk", C.c_float), ("steps_nearest", C.c_uint64), ("steps_shadow", C.c_uint64),
+                ("state_cases", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}

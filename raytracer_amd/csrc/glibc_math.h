@@ -7,6 +7,18 @@
 // e_asinf.c: the fdlibm float kernels; no FMA variants exist for them), which on correctly rounded +, -, *, /, sqrt without
 // contraction -- what this library is compiled for -- give the same bits on the device as in glibc.  tests/test_glibc_math.py
 // compiles this header with g++ and compares it with the host's libm on 20 M random arguments and on every float in [-1, 1].
+//
+// The algorithms and constants below are those of the fdlibm float kernels as glibc carries them (s_atanf.c, e_atan2f.c, e_asinf.c:
+// "Conversion to float by Ian Lance Taylor, Cygnus Support"), whose notice reads:
+//
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//
+//   Developed at SunPro, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
 #pragma once
 #include <stdint.h>
 #include <string.h>

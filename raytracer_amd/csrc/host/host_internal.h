@@ -23,6 +23,9 @@ struct FlatSceneStore {
 	std::vector<uint8_t> texels;
 	std::vector<rt_bvh_node> bvh_nodes;
 	std::vector<uint32_t> leaf_prims;
+	// which optional camera keys the scene file carried (raytracer.cpp:136-143 prints a line for each one present); not part of
+	// the flat form on disk: a scene read from an .rtscene file reports neither
+	bool hasCameraField = false, hasCameraBackground = false;
 	FlatSceneStore() : view() {}
 	void link();   // points the view at the vectors
 	static FlatSceneStore* from_view(rt_flat_scene* v) { return reinterpret_cast<FlatSceneStore*>(v); }

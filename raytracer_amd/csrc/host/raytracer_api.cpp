@@ -54,8 +54,18 @@ void rtapi_choose_scene(const char* fn) {
 	if (g_scene) rt_scene_free(g_scene);
 	if (g_flat) rt_flat_scene_free(g_flat);
 	g_flat = flat; g_scene = nullptr;
-	fov = flat->fov;
-	for (int i = 0; i < 3; i++) background_colour.v[i] = flat->background[i];
+	// raytracer.cpp:134-143: both keys are optional, and each one present is announced (glm::to_string(vec3) is "vec3(%f, %f, %f)")
+	const rt::FlatSceneStore* store = rt::FlatSceneStore::from_view(flat);
+	if (store->hasCameraField) {
+		fov = flat->fov;
+		std::cout << "Setting fov to " << fov << " degrees.\n";
+	}
+	if (store->hasCameraBackground) {
+		for (int i = 0; i < 3; i++) background_colour.v[i] = flat->background[i];
+		char text[96];
+		snprintf(text, sizeof text, "vec3(%f, %f, %f)", background_colour.v[0], background_colour.v[1], background_colour.v[2]);
+		std::cout << "Setting background colour to " << text << std::endl;
+	}
 	const char* dev = getenv("RT_DEVICE");
 	rc = rt_scene_upload(flat, dev ? atoi(dev) : 0, &g_scene);
 	if (rc != RT_OK) {

@@ -317,8 +317,8 @@ struct Loader {
 		rt_flat_scene& V = S->view;
 		V.fov = 60; V.background[0] = V.background[1] = V.background[2] = 0;   // raytracer.cpp:24-25
 		const Value& camera = scene["camera"];
-		if (camera.has("field")) V.fov = camera["field"].number();
-		if (camera.has("background")) put3(V.background, to_vec3(camera["background"]));
+		if (camera.has("field")) { V.fov = camera["field"].number(); S->hasCameraField = true; }
+		if (camera.has("background")) { put3(V.background, to_vec3(camera["background"])); S->hasCameraBackground = true; }
 
 		// material 0 = Material() for csg leaves; object k uses material k+1
 		rt_material zero; memset(&zero, 0, sizeof zero);

@@ -62,7 +62,7 @@ int rt_view_reshape(rt_view* v, int width, int height) {   // q1.cpp:278-288
 }
 
 // keyboard(), q1.cpp:179-247.  Returns 1 if the key starts a new frame (drawing_y = 0), 0 if not, -1 for Escape (the reference exits),
-// -2 on a bad argument; *text_len receives the length of what the reference prints on std::cout for this key (`p`, `l`), written to text.
+// -2 on a bad argument (a NULL view); *text_len receives the length of what the reference prints on std::cout for this key (`p`, `l`), written to text.
 int rt_view_key(rt_view* v, unsigned char key, char* text, size_t cap, size_t* text_len) {
 	if (text && cap > 0) text[0] = 0;
 	if (text_len) *text_len = 0;
@@ -153,8 +153,11 @@ int rt_view_click(rt_view* v, int x, int y_from_top, char* text, size_t cap, siz
 	if (text_len) *text_len = 0;
 	if (!v || !v->scene) { rt::set_error("rt_view_click: bad argument"); return RT_EINVAL; }
 	const int y = v->height - y_from_top - 1;
-	const rt_camera& c = v->basis;   // s(x, y) with the basis of the frame on screen (q1.cpp:51-53)
-	const vec3 eye(c.eye[0], c.eye[1], c.eye[2]), facing(c.facing[0], c.facing[1], c.facing[2]), right(c.right[0], c.right[1], c.right[2]), up(c.up[0], c.up[1], c.up[2]);
+	// s(x, y), q1.cpp:51-53, reads the globals as they are NOW: `eye` is moved by the w/s/a/d/t/g keys at once, while facing / camera_right /
+	// camera_up are only rewritten by the next display() (setFacing, q1.cpp:111-120).  A click between a move key and the next frame
+	// therefore starts at the moved eye with the basis of the frame still on screen -- and so does trace(eye, uvw, ...), q1.cpp:259.
+	const rt_camera& c = v->basis;
+	const vec3 eye = v->eye, facing(c.facing[0], c.facing[1], c.facing[2]), right(c.right[0], c.right[1], c.right[2]), up(c.up[0], c.up[1], c.up[2]);
 	const vec3 uvw = eye + facing + right * (2 * ((x + 0.5f) / v->width - 0.5f)) + up * (2 * ((y + 0.5f) / v->height - 0.5f));
 	std::vector<rt_pick_event> ev(1u << 16);
 	size_t n = 0;

@@ -80,6 +80,7 @@ int staticScratchFor(int device, StaticScratch** out) {
 struct rt_scene {
 	int device = 0;
 	StaticScratch* staticScratch = nullptr;   // this device's copy of `scratch` (rt_intersect_batch_static)
+	bool staticWarm = false;                  // rt_intersect_batch_static has run once on this handle outside a stream capture (its kernel variants loaded, their occupancy cached); under mtx
 	DevScene dev{};
 	bool hasCsg = false;
 	int nCsg = 0;                   // CSG objects in the scene (rtk_shadow_area: few enough to defer their evaluation)
@@ -689,6 +690,7 @@ struct Run {
 	rt_stats stats{};
 	RtPick pick{ nullptr, nullptr, 0 };   // rt_trace_pick: where the narration's events go
 	uint32_t texRecords = 0;               // RtTexFix records the current batch has left so far
+	uint32_t stateCases = 0;               // failed exit searches since begin() (the lane's counter is cumulative over the call's batches)
 
 	// Which traversal form a level uses.  Level 0 of a frame (and its shadow rays) is coherent by construction: 64
 	// consecutive queue slots are an 8x8 pixel block.  Deeper levels and caller-supplied rays are walked per lane.
@@ -727,7 +729,7 @@ struct Run {
 			if (timeK) HIPCHK(hipEventRecord(ln->ev[3], st));
 			rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, n, ln->ray[cur ^ 1], ln->surfq, ln->transq, ln->ctr, sc->accum, aaSq, maxDepth,
 			          sc->shadowRaysPerSurface > 0, level == 0 ? src.outHit : nullptr, src.outId, src.outT, pick, sc->texFix(*ln));
-			if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, n, ln->ray[cur ^ 1], ln->ctr, sc->accum, aaSq, maxDepth, pick);
+			if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, n, ln->ray[cur ^ 1], ln->ctr, &ln->ctr->state_cases, sc->accum, aaSq, maxDepth, pick);
 			// Level 0 of a frame lit by point-type lights only: the shadow packets are queued before the host has seen the
 			// counts (the kernels read them on the device), and the host waits for the count read-back while they run --
 			// the lane's stream never idles through a host round trip.
@@ -746,6 +748,7 @@ struct Run {
 				if (shadowPending) { HIPCHK(hipEventElapsedTime(&ms, ln->ev[4], ln->ev[5])); stats.shadow_ms += ms; shadowPending = false; }
 			}
 			texRecords = ln->ctrHost->texrec_count;
+			stateCases = ln->ctrHost->state_cases;   // (cumulative since begin())
 			if (ln->ctrHost->overflow) return 1;
 			nLevels++;
 			// inactive slots of a partial edge tile are not rays
@@ -785,19 +788,38 @@ struct Run {
 	// records' counter is one per batch (RtTexFix::count) and k_publish reports it with every level.
 	// Waits until k_publish has written the report queued with sequence number `seq`.  Spins for a while (the levels this loop is
 	// for take tens of microseconds), then sleeps between looks; a GPU error or ten seconds without the report end the wait.
-	int awaitReport(const RtLevelReport* slot, uint32_t seq, RtLevelReport& out) {
+	// `level`: which level's report this is (for the message when it does not come).  Two ways to give up: the stream has gone idle
+	// and ten seconds later the report is still missing (it was lost), or the stream is still busy after RT_LEVEL_TIMEOUT_S seconds
+	// (default 120: a kernel of that level, or of one queued before it, is not finishing) -- the error then names the level and the
+	// kernels that were queued for it, so that rt_last_error() says where the lane hung instead of the worker waiting for ever.
+	int awaitReport(const RtLevelReport* slot, uint32_t seq, RtLevelReport& out, int level, bool packets) {
+		static const uint32_t limitS = std::max<uint32_t>(1, envU32("RT_LEVEL_TIMEOUT_S", 120));
 		const auto t0 = std::chrono::steady_clock::now();
+		auto what = [&] {
+			std::string k = packets ? "k_intersect_packet" : "k_intersect";
+			k += ", k_shade";
+			if (sc->hasTransmissive) k += ", k_transmit";
+			k += ", k_publish";
+			return "level " + std::to_string(level) + " of the ray tree (" + k + ")";
+		};
 		for (uint64_t spins = 0;; spins++) {
 			if (__atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) == seq) {
-				out.next_count = slot->next_count; out.surf_count = slot->surf_count; out.overflow = slot->overflow; out.texrec_count = slot->texrec_count; out.seq = seq;
+				out.next_count = slot->next_count; out.surf_count = slot->surf_count; out.overflow = slot->overflow; out.texrec_count = slot->texrec_count; out.state_cases = slot->state_cases; out.seq = seq;
 				return RT_OK;
 			}
 			if (spins < 4000) { __builtin_ia32_pause(); continue; }
 			if ((spins & 63) == 0) {
 				const hipError_t e = hipStreamQuery(st);
-				if (e != hipSuccess && e != hipErrorNotReady) { rt::set_error(std::string("waiting for a level's counts: ") + hipGetErrorString(e)); return RT_EHIP; }
-				if (e == hipSuccess && __atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) != seq &&
-				    std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) { rt::set_error("a level's counts never arrived"); return RT_EHIP; }
+				if (e != hipSuccess && e != hipErrorNotReady) { rt::set_error("waiting for the counts of " + what() + ": " + hipGetErrorString(e)); return RT_EHIP; }
+				const auto waited = std::chrono::steady_clock::now() - t0;
+				if (e == hipSuccess && __atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) != seq && waited > std::chrono::seconds(10)) {
+					rt::set_error("the counts of " + what() + " never arrived although the stream is idle");
+					return RT_EHIP;
+				}
+				if (e == hipErrorNotReady && waited > std::chrono::seconds(limitS)) {
+					rt::set_error("the stream is still busy " + std::to_string(limitS) + " s after queueing " + what() + ": a kernel of that level or of the shadow launches before it is not finishing (RT_LEVEL_TIMEOUT_S)");
+					return RT_EHIP;
+				}
 			}
 			std::this_thread::sleep_for(std::chrono::microseconds(spins < 8000 ? 5 : 50));
 		}
@@ -834,9 +856,9 @@ struct Run {
 				rtk_intersect(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketNear : sc->maxBlocks, ln->ray[cur], nb, ln->hitq, &L[lv], nDev);
 				rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, nb, ln->ray[cur ^ 1], ln->surfq, ln->transq, &L[lv], sc->accum, aaSq, maxDepth,
 				          shadows, lv == 0 ? src.outHit : nullptr, src.outId, src.outT, pick, sc->texFix(*ln), nDev);
-				if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, nb, ln->ray[cur ^ 1], &L[lv], sc->accum, aaSq, maxDepth, pick);
+				if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, nb, ln->ray[cur ^ 1], &L[lv], &ln->ctr->state_cases, sc->accum, aaSq, maxDepth, pick);
 				seqOf[lv] = ++ln->reportSeq ? ln->reportSeq : ++ln->reportSeq;   // (never 0)
-				rtk_publish(st, &L[lv], sc->texelFix ? &ln->ctr->texrec_count : nullptr, ln->reportDev + lv, seqOf[lv]);
+				rtk_publish(st, &L[lv], sc->texelFix ? &ln->ctr->texrec_count : nullptr, sc->hasTransmissive ? &ln->ctr->state_cases : nullptr, ln->reportDev + lv, seqOf[lv]);
 				if (shadows) {
 					if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nb, sc->pointLights, sc->nPointLights, sc->accum, aaSq, &L[lv], true, sc->maxBlocksPacketShadow2);
 					for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, sc->nCsg, false, ln->surfq, nb, al.first, al.second, seed, sc->accum, aaSq, &L[lv], true);
@@ -848,12 +870,13 @@ struct Run {
 			if (read == queued) break;     // nothing in flight that the host has not seen
 			// the counts of the oldest level not yet read
 			RtLevelReport c;
-			if (int rcW = awaitReport(ln->report + read, seqOf[read], c)) return rcW;
+			if (int rcW = awaitReport(ln->report + read, seqOf[read], c, read, coherent(read))) return rcW;
 			nearRays += known;
 			nLevels++;
 			shadowRays += (uint64_t)std::min<uint32_t>(c.surf_count, sc->qcap) * sc->shadowRaysPerSurface;
 			if (c.overflow) overflow = true;
 			texRecords = c.texrec_count;   // (records of every level up to this one: k_publish runs behind the level's shading)
+			stateCases = c.state_cases;    // (failed exit searches since begin(): k_publish runs behind the level's k_transmit)
 			known = overflow ? 0 : std::min<uint32_t>(c.next_count, sc->qcap);
 			read++;
 			if (read > lastLevel) known = 0;
@@ -896,6 +919,8 @@ struct Run {
 			const uint32_t cnt = (uint32_t)std::min<uint64_t>(perBatch, totalRays - r0);
 			if (int rc = batch((uint32_t)r0, cnt)) return rc;
 		}
+		// (a batch that overflowed and was re-run in halves counted its failed searches twice: the count is then an upper bound)
+		stats.state_cases = stateCases;
 		return RT_OK;
 	}
 };
@@ -1126,7 +1151,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 			int qlevels = buildQuadTreelets(s, aug, embedQ, quads, quadRuns, quadDepth);
 			if (qlevels > RT_TREELET_MAX_LEVELS) qlevels = buildQuadTreelets(s, aug, false, quads, quadRuns, quadDepth);
 			if (qlevels < 0) return fail(RT_EINVAL);
-			if (qlevels > RT_TREELET_MAX_LEVELS || quads.size() / RT_QUAD_SLOTS >= RT_TREELET_CONS / RT_QUAD_SLOTS || 3 * quadDepth + 1 > RT_PACKET_STACK_DEPTH) {
+			if (qlevels > RT_TREELET_MAX_LEVELS || quads.size() / RT_QUAD_SLOTS >= RT_TREELET_CONS / RT_QUAD_SLOTS || !RT_PACKET_STACK_FITS(quadDepth)) {
 				rt::set_error("BVH too deep or too large for the quad-node layout"); return fail(RT_ELIMIT);
 			}
 			if (timing) fprintf(stderr, "[upload] quads: %zu treelets, %d levels, depth %d\n", quads.size() / RT_QUAD_SLOTS, qlevels, quadDepth);
@@ -1297,7 +1322,7 @@ int rt_render_wait(rt_scene* sc, uint64_t ticket, rt_stats* stats) {
 		total.rays_nearest += p.rays_nearest; total.rays_shadow += p.rays_shadow; total.batch_splits += p.batch_splits;
 		total.nodes_nearest += p.nodes_nearest; total.prims_nearest += p.prims_nearest; total.nodes_shadow += p.nodes_shadow; total.prims_shadow += p.prims_shadow;
 		total.nearest_ms += p.nearest_ms; total.shadow_ms += p.shadow_ms; total.steps_nearest += p.steps_nearest; total.steps_shadow += p.steps_shadow;
-		total.levels = std::max(total.levels, p.levels); total.max_walk = std::max(total.max_walk, p.max_walk);
+		total.levels = std::max(total.levels, p.levels); total.max_walk = std::max(total.max_walk, p.max_walk); total.state_cases += p.state_cases;
 	}
 	retire();
 	if (e != hipSuccess) { rt::set_error(std::string("rt_render_wait: ") + hipGetErrorString(e)); return RT_EHIP; }
@@ -1432,10 +1457,23 @@ int rt_intersect_batch_static(rt_scene* sc, const float* e_dev, const float* d_d
 	if (!sc || (n > 0 && (!e_dev || !d_dev))) { rt::set_error("rt_intersect_batch_static: bad argument"); return RT_EINVAL; }
 	if (n > RT_STATIC_MAX_RAYS) { rt::set_error("rt_intersect_batch_static: more than RT_STATIC_MAX_RAYS rays in one call (the scratch is a fixed device array; split the batch)"); return RT_ELIMIT; }
 	if (n == 0) return RT_OK;
-	sc->drain();   // frames in flight use the same traversal kernels' cursors only through their own lanes, but the call promises "after outstanding frames"
 	HIPCHK(hipSetDevice(sc->device));
-	StaticScratch* ws = sc->staticScratch;   // device address (hipGetSymbolAddress), never the array's name
 	hipStream_t st = static_cast<hipStream_t>(stream);
+	// Under stream capture nothing here may wait for, or ask about, device work: the drain below blocks the host on the events of frames
+	// in flight, and the first call on a device loads the kernels and asks the runtime for their occupancy.  So a capturing caller must
+	// have no frame in flight and must have made one ordinary call on this handle before (both refused with RT_EINVAL otherwise); what
+	// is left -- one memset and three launches on `stream` -- is what the graph records.
+	hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+	if (st) HIPCHK(hipStreamIsCapturing(st, &capture));
+	if (capture == hipStreamCaptureStatusActive) {
+		std::unique_lock<std::mutex> g(sc->mtx);
+		bool busy = false;
+		for (const rt_scene::Job& j : sc->jobs) busy |= j.id != 0;
+		if (busy) { rt::set_error("rt_intersect_batch_static: frames are in flight (or not yet waited for) while the stream is capturing; wait for them first"); return RT_EINVAL; }
+		if (!sc->staticWarm) { rt::set_error("rt_intersect_batch_static: the first call on a scene handle loads its kernels and cannot be captured; make one call outside the capture first"); return RT_EINVAL; }
+	} else
+	sc->drain();   // frames in flight use the same traversal kernels' cursors only through their own lanes, but the call promises "after outstanding frames"
+	StaticScratch* ws = sc->staticScratch;   // device address (hipGetSymbolAddress), never the array's name
 	const RtQueue rq{ ws->ray, RT_STATIC_MAX_RAYS }, hq{ ws->hit, RT_STATIC_MAX_RAYS };
 	// the array keeps the last call's contents: the work cursor and the queue counts must start at zero; the queue slots
 	// [0, n) are all rewritten by k_load_rays / k_intersect before they are read
@@ -1444,6 +1482,7 @@ int rt_intersect_batch_static(rt_scene* sc, const float* e_dev, const float* d_d
 	rtk_intersect(st, sc->dev, sc->hasCsg, false, false, sc->maxBlocks, rq, (uint32_t)n, hq, &ws->ctr);
 	rtk_export_hits(st, sc->dev, hq, (uint32_t)n, hit_dev, obj_id_dev, t_dev);
 	if (int rcL = launchesOk()) return rcL;
+	if (capture != hipStreamCaptureStatusActive) { std::lock_guard<std::mutex> g(sc->mtx); sc->staticWarm = true; }
 	return RT_OK;
 }
 

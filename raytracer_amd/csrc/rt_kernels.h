@@ -65,6 +65,14 @@
 #define RT_QUAD_TREELET_BYTES (RT_QUAD_SLOTS * 64)
 /* aux of an embedded run in the quad form: count << 26 | RT_TREELET_EMBED | level << RT_QUAD_SLOT_BITS | slot */
 #define RT_PACKET_STACK_DEPTH 48   /* wave stack entries: a step of the quad walk leaves up to three behind, the tree is at most 15 quads deep */
+/* The pushes of the packet walks (RT_Q_PUSH in rt_kernels.hip) and the deferred-CSG slots skip an entry that finds the stack full: a
+ * wrong image with no error.  That cannot happen while these two bounds hold, and rt_scene_upload / rtk_shadow_area check them with
+ * THESE macros, so the walks and their guards cannot drift apart: a quad step leaves at most three entries behind and then descends,
+ * so a tree `quadDepth` quads deep needs 3 * quadDepth + 1 entries; a CSG leaf is met once per packet, so deferral needs one slot
+ * per CSG object of the scene. */
+#define RT_PACKET_STACK_NEED(quadDepth) (3 * (quadDepth) + 1)
+#define RT_PACKET_STACK_FITS(quadDepth) (RT_PACKET_STACK_NEED(quadDepth) <= RT_PACKET_STACK_DEPTH)
+#define RT_PACKET_DEFER_FITS(nCsg) ((nCsg) <= RT_PACKET_STACK_DEPTH)
 #define RT_PACKET_STACK_BYTES (RT_PACKET_STACK_DEPTH * 32)   /* 32 B per entry: the two-ray shadow walk carries two lane masks */
 // LDS of a packet kernel's workgroup: the root treelet once (every packet starts there; fetched when the workgroup
 // starts), then per wave one 1 KB buffer per deeper treelet level, one more when the scene has external runs to stage,
@@ -98,7 +106,7 @@ struct RtCounters {
 	uint32_t overflow;        // an append found its queue full (the batch is re-run in halves)
 	uint32_t pad;
 	uint32_t texrec_count;    // RtTexFix records appended by k_shade since k_texel_reset (all levels of a batch)
-	uint32_t pad2;
+	uint32_t state_cases;     // exit searches of k_transmit that found no exit since the call began (rt_stats::state_cases); in the lane's base block
 	unsigned long long nodes_nearest, prims_nearest;   // RT_FLAG_COUNTERS: 64 B nodes read / primitive tests in k_intersect
 	unsigned long long nodes_shadow, prims_shadow;     // ... and in the shadow kernels
 	unsigned long long steps_nearest, steps_shadow;    // RT_FLAG_COUNTERS: node steps of the packet walks (one per wave and node, whatever the number of rays in it)
@@ -110,7 +118,7 @@ struct RtCounters {
 };
 
 // what k_publish leaves in host memory for one level (Run::levelsAhead polls seq)
-struct RtLevelReport { uint32_t next_count, surf_count, overflow, texrec_count, seq; };   // texrec_count: RtTexFix records of the batch up to and including this level
+struct RtLevelReport { uint32_t next_count, surf_count, overflow, texrec_count, state_cases, seq; };   // texrec_count: RtTexFix records of the batch up to and including this level; state_cases: failed exit searches of the call so far
 
 // Texel state of textured triangles (texturemesh.cpp:49-50, objects.cpp:62-79): TextureTriangle::lightPoint writes the texel into the
 // triangle's own material and Object::lightPoint reads it back only after it has traced the reflected ray, so a hit whose reflection
@@ -137,7 +145,8 @@ void rtk_intersect(hipStream_t st, const DevScene& S, bool csg, bool count, bool
 void rtk_export_hits(hipStream_t st, const DevScene& S, RtQueue hq, uint32_t n, uint8_t* hit, int32_t* id, float* t);
 // rt_trace_pick: where the shading and transmit kernels leave the events of the narration (null ev: no narration)
 struct RtPick { rt_pick_event* ev; uint32_t* count; uint32_t cap; };
-void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint32_t maxRequests, RtQueue nq, RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth,
+// stateCases: where failed exit searches are counted (rt_stats::state_cases; the lane's base counter block, not the level's)
+void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint32_t maxRequests, RtQueue nq, RtCounters* ctr, uint32_t* stateCases, RtAccum A, uint32_t aaSq, int maxDepth,
                   RtPick pick = RtPick{ nullptr, nullptr, 0 });
 void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
                uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick = RtPick{ nullptr, nullptr, 0 },
@@ -152,4 +161,4 @@ void rtk_shadow_query(hipStream_t st, const DevScene& S, bool csg, const float* 
 void rtk_resolve(hipStream_t st, RtAccum A, int W, int H, int tileRank, int tileRanks, uint32_t lp0, uint32_t count, uint32_t aaSq, int linear, float* rgb);
 void rtk_tiles_copy(hipStream_t st, const float* src, float* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode);
 void rtk_tiles_rgb8(hipStream_t st, const void* src, uint8_t* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode);
-void rtk_publish(hipStream_t st, const RtCounters* ctr, const uint32_t* texCount, RtLevelReport* hostMapped, uint32_t seq);
+void rtk_publish(hipStream_t st, const RtCounters* ctr, const uint32_t* texCount, const uint32_t* stateCount, RtLevelReport* hostMapped, uint32_t seq);

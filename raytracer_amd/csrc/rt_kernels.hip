@@ -731,6 +731,7 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			// The entry to go on with: the nearest one for the wave's first ray (nearest-hit walk), the first one any ray passed (shadow
 			// rays: any order is correct).  The other entries that some ray passed wait on the stack.  Written out per case: the entry's
 			// words are in scalar registers, and picking them by a run-time index costs more instructions than the step's box tests.
+			// (sp < RT_PACKET_STACK_DEPTH always holds: rt_scene_upload refuses a tree that does not pass RT_PACKET_STACK_FITS, rt_kernels.h)
 #define RT_Q_PUSH(i) do { if (Q.m[i] != 0 && sp < RT_PACKET_STACK_DEPTH) { *reinterpret_cast<uint4*>(L.stack[sp]) = make_uint4((uint32_t)Q.c[i], (uint32_t)Q.m[i], (uint32_t)(Q.m[i] >> 32), Q.inf[i]); sp++; } } while (0)
 #define RT_Q_TAKE(i) do { node = Q.c[i]; info = Q.inf[i]; inSub = ((Q.m[i] >> lane) & 1ull) != 0; popNext = false; } while (0)
 			uint32_t first;
@@ -778,7 +779,7 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 				const uint32_t entry = *(cuint32*)(uintptr_t)(S.leaf_prims + at);
 				if (DEFER && RT_PRIM_TYPE(entry & ~RT_PRIM_LAST) == RT_PRIM_CSG) {   // (wave-uniform)
 					const unsigned long long m = __ballot(inSub && T.lit);
-					if (m != 0 && nDeferred < RT_PACKET_STACK_DEPTH) {
+					if (m != 0 && nDeferred < RT_PACKET_STACK_DEPTH) {   // (always: DEFER variants are launched only when RT_PACKET_DEFER_FITS, rtk_shadow_area)
 						if (lane == 0) reinterpret_cast<uint4*>(L.stack[nDeferred])[1] = make_uint4(entry & ~RT_PRIM_LAST, (uint32_t)m, (uint32_t)(m >> 32), (uint32_t)at + 1u);
 						nDeferred++;
 					}
@@ -1210,7 +1211,7 @@ __device__ __forceinline__ void pickEmit(const RtPick& P, uint32_t path, int kin
 // ---------------------------------------------------------------------------------------------------------
 template <bool CSG, bool PICK, class Store>
 __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refraction, f3 inPoint, f3 inVector, f3 inNormal, f3& outPoint, f3& outVector, Store& csgStore,
-                                   const RtPick& pick, uint32_t path) {
+                                   const RtPick& pick, uint32_t path, uint32_t& failedSearches) {
 	const uint32_t type = RT_PRIM_TYPE(ref), ix = RT_PRIM_INDEX(ref);
 	if (type == RT_PRIM_PLANE || refraction == 0) {
 		outVector = inVector;
@@ -1230,9 +1231,11 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 	int reflections = 0;
 	while (!result && reflections < RT_MAX_REFLECTIONS) {
 		f3 hp = currentPoint;
+		float tExit = 0.0f;   // (what the oracle counts as a hidden-state case: an exit search with no exit, restate.cpp transmitRay)
 		if (type == RT_PRIM_SPHERE) {
 			const rt_sphere s = S.spheres[ix];
 			const float t = sphereHit(ld3(s.center), s.radius, currentPoint, innerVector, true);
+			tExit = t;
 			// cachedHitpoint is rewritten whenever rayhit gets past its two early returns; t == 0 can be either
 			// "missed" (no write) or "exactly at the origin" (write of e + 0*d = e): both leave hp == currentPoint.
 			if (t > 0.0f) hp = currentPoint + t * innerVector;
@@ -1242,17 +1245,23 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 			const float t = meshHit(S, S.tris[ix].mesh, currentPoint, innerVector, true, nrm);
 			if (t > 0.0f) hp = currentPoint + t * innerVector;
 			outNormal = nrm;
+			tExit = t;
 		} else if (type == RT_PRIM_BOX) {
 			const rt_box b = S.boxes[ix];
 			const float t = boxIntersect(b.b, currentPoint, innerVector, true);
 			if (!(t < 0)) hp = currentPoint + t * innerVector;
 			boxNormal(b.b, hp, outNormal);
+			tExit = t;
 		} else if (CSG) {
 			uint32_t tag = 0;
 			const float t = csgEval(S, c, currentPoint, innerVector, true, tag, csgStore);
 			hp = currentPoint + t * innerVector;   // csgObject::rayhit always rewrites cachedHitpoint (csg.cpp:24)
 			if (t != 0.0f) outNormal = csgNormal(S, c, currentPoint, innerVector, tag, csgStore);
+			tExit = t;
 		}
+		// objects.cpp:123-125: the reference goes on from whatever the object's hit cache holds -- for a top-level mesh that is state left by
+		// EARLIER pixels, which the device does not have.  Counted, so that a caller can report the fraction.
+		if (!(tExit > 0.0f)) failedSearches++;
 		outPoint = hp;
 		result = refractRay(innerVector, outNormal, refraction, outVector);
 		if (!result) {
@@ -1453,7 +1462,7 @@ __global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX || MULTI) ? 1 : 8) v
 // largest program fits (CsgLds; rtk_transmit decides).
 constexpr int kTransmitBlock = 64;
 template <bool CSG, bool LDSCSG, bool PICK>
-__global__ __launch_bounds__(kTransmitBlock) void k_transmit(DevScene S, RtQueue tq, RtQueue nq, RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth, RtPick pick) {
+__global__ __launch_bounds__(kTransmitBlock) void k_transmit(DevScene S, RtQueue tq, RtQueue nq, RtCounters* ctr, uint32_t* stateCases, RtAccum A, uint32_t aaSq, int maxDepth, RtPick pick) {
 	extern __shared__ __align__(16) uint8_t transmitLds[];
 	const uint32_t i = blockIdx.x * kTransmitBlock + threadIdx.x;
 	const uint32_t n = ctr->trans_count < tq.cap ? ctr->trans_count : tq.cap;
@@ -1470,13 +1479,15 @@ __global__ __launch_bounds__(kTransmitBlock) void k_transmit(DevScene S, RtQueue
 		pixKey = qu(tq, TQ_PIX, i); path = qu(tq, TQ_PATH, i);
 		f3 outPoint, outVector;
 		bool ok;
+		uint32_t failedSearches = 0;
 		if constexpr (CSG && LDSCSG) {
 			CsgLds store = csgLdsStore(transmitLds, kTransmitBlock, (int)threadIdx.x, S.csg_cap);
-			ok = transmitRay<CSG, PICK>(S, prim, qf(tq, TQ_REFR, i), p, d, N, outPoint, outVector, store, pick, path);
+			ok = transmitRay<CSG, PICK>(S, prim, qf(tq, TQ_REFR, i), p, d, N, outPoint, outVector, store, pick, path, failedSearches);
 		} else {
 			CsgScratch store;
-			ok = transmitRay<CSG, PICK>(S, prim, qf(tq, TQ_REFR, i), p, d, N, outPoint, outVector, store, pick, path);
+			ok = transmitRay<CSG, PICK>(S, prim, qf(tq, TQ_REFR, i), p, d, N, outPoint, outVector, store, pick, path, failedSearches);
 		}
+		if (failedSearches != 0u) atomicAdd(stateCases, failedSearches);   // (rare: a handful per frame)
 		if (PICK) pickEmit(pick, path, ok ? RT_PICK_EXIT : RT_PICK_LOST, 0, 0, ok ? outPoint : mk3(0, 0, 0));   // objects.cpp:90-92, 100-101
 		if (ok) {
 			tO = outPoint;
@@ -2010,9 +2021,10 @@ __global__ __launch_bounds__(kBlock) void k_tiles_rgb8(const void* src, uint8_t*
 // The counts of a level, written straight into host memory (pinned, mapped) for the host loop that runs ahead of the GPU: one
 // 64-thread launch instead of a copy and an event in the stream, and the host sees them as soon as the store lands instead of
 // after a copy engine and an interrupt.  `seq` (never 0) goes last, behind a system-scope fence: the host polls it.
-__global__ __launch_bounds__(64) void k_publish(const RtCounters* ctr, const uint32_t* texCount, RtLevelReport* host, uint32_t seq) {
+__global__ __launch_bounds__(64) void k_publish(const RtCounters* ctr, const uint32_t* texCount, const uint32_t* stateCount, RtLevelReport* host, uint32_t seq) {
 	if (threadIdx.x != 0) return;
 	host->texrec_count = texCount ? *texCount : 0u;
+	host->state_cases = stateCount ? *stateCount : 0u;
 	host->next_count = ctr->next_count;
 	host->surf_count = ctr->surf_count;
 	host->overflow = ctr->overflow;
@@ -2132,19 +2144,19 @@ void rtk_texel_fix(hipStream_t st, const DevScene& S, bool csg, RtTexFix tex, ui
 	}
 	RT_LAUNCH(k_texel_reset, count, st, tex, count, ctr, aaSq);
 }
-void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint32_t maxRequests, RtQueue nq, RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth, RtPick pick) {
+void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint32_t maxRequests, RtQueue nq, RtCounters* ctr, uint32_t* stateCases, RtAccum A, uint32_t aaSq, int maxDepth, RtPick pick) {
 	if (maxRequests == 0) return;
 	const dim3 grid((maxRequests + kTransmitBlock - 1) / kTransmitBlock), block(kTransmitBlock);
 	const size_t lds = RTD_CSG_LDS_BYTES(kTransmitBlock, S.csg_cap, S.csg_nodes_max);
 	static const bool noLds = getenv("RT_NO_CSG_LDS") != nullptr;
 	if (pick.ev) {   // rt_trace_pick: one ray tree, no need for the LDS lists
-		if (csg) RT_LAUNCH_RAW((k_transmit<true, false, true>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
-		else RT_LAUNCH_RAW((k_transmit<false, false, true>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
+		if (csg) RT_LAUNCH_RAW((k_transmit<true, false, true>), grid, block, 0, st, S, tq, nq, ctr, stateCases, A, aaSq, maxDepth, pick);
+		else RT_LAUNCH_RAW((k_transmit<false, false, true>), grid, block, 0, st, S, tq, nq, ctr, stateCases, A, aaSq, maxDepth, pick);
 		return;
 	}
-	if (!csg) RT_LAUNCH_RAW((k_transmit<false, false, false>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
-	else if (lds <= 64u * 1024u && !noLds) RT_LAUNCH_RAW((k_transmit<true, true, false>), grid, block, lds, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
-	else RT_LAUNCH_RAW((k_transmit<true, false, false>), grid, block, 0, st, S, tq, nq, ctr, A, aaSq, maxDepth, pick);
+	if (!csg) RT_LAUNCH_RAW((k_transmit<false, false, false>), grid, block, 0, st, S, tq, nq, ctr, stateCases, A, aaSq, maxDepth, pick);
+	else if (lds <= 64u * 1024u && !noLds) RT_LAUNCH_RAW((k_transmit<true, true, false>), grid, block, lds, st, S, tq, nq, ctr, stateCases, A, aaSq, maxDepth, pick);
+	else RT_LAUNCH_RAW((k_transmit<true, false, false>), grid, block, 0, st, S, tq, nq, ctr, stateCases, A, aaSq, maxDepth, pick);
 }
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,
                       RtAccum A, uint32_t aaSq, RtCounters* ctr, bool countOnDevice, int maxBlocksPairs) {
@@ -2185,7 +2197,7 @@ void rtk_shadow_area(hipStream_t st, const DevScene& S, bool csg, int nCsg, bool
 	const int cod = countOnDevice ? 1 : 0;
 	const unsigned long long items = (unsigned long long)nsurf * samples;
 #define RT_AREA(...) RT_LAUNCH_S((k_shadow_area<__VA_ARGS__>), items, packetLdsBytes(S), st, S, sq, nsurf, lightIndex, seed, A, aaSq, ctr, cod)
-	const bool defer = csg && nCsg <= RT_PACKET_STACK_DEPTH && getenv("RT_NO_CSG_DEFER") == nullptr;   // (the switch: for the tests, read per call)
+	const bool defer = csg && RT_PACKET_DEFER_FITS(nCsg) && getenv("RT_NO_CSG_DEFER") == nullptr;   // (the switch: for the tests, read per call)
 	if (samples % 64u == 0u) {   // every wave is one surface
 		if (defer) { if (count) RT_AREA(true, true, true, true); else RT_AREA(true, false, true, true); }
 		else if (csg) { if (count) RT_AREA(true, true, true, false); else RT_AREA(true, false, true, false); }
@@ -2210,6 +2222,6 @@ void rtk_tiles_copy(hipStream_t st, const float* src, float* dst, int W, int H, 
 void rtk_tiles_rgb8(hipStream_t st, const void* src, uint8_t* dst, int W, int H, int tileRank, int tileRanks, uint32_t count, int mode) {
 	RT_LAUNCH(k_tiles_rgb8, count, st, src, dst, W, H, tileRank, tileRanks, count, mode);
 }
-void rtk_publish(hipStream_t st, const RtCounters* ctr, const uint32_t* texCount, RtLevelReport* hostMapped, uint32_t seq) {
-	RT_LAUNCH_RAW(k_publish, dim3(1), dim3(64), 0, st, ctr, texCount, hostMapped, seq);
+void rtk_publish(hipStream_t st, const RtCounters* ctr, const uint32_t* texCount, const uint32_t* stateCount, RtLevelReport* hostMapped, uint32_t seq) {
+	RT_LAUNCH_RAW(k_publish, dim3(1), dim3(64), 0, st, ctr, texCount, stateCount, hostMapped, seq);
 }

@@ -39,6 +39,11 @@ def test_bench_line_with_several_ranks_sharing_one_gpu(ranks):
     assert out["config"]["rays_per_step"] >= ranks * 960 * 540
     assert out["value"] > 0 and out["roofline"]["launch_ms"] > 0 and out["cpu_baseline"] is None
     assert out["exchange"] == ("rgb8" if ranks == 3 else "f32")
+    # the timed region: blocks of exactly `steps` frames repeated until half a second has gone by, the median block reported
+    assert out["blocks"] >= 1 and out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
+    # the same N-samples-per-pixel frame on one GPU alone, and the efficiency that follows from it (not from value(1), whose frame is another)
+    assert out["one_gpu_same_workload_ms"] > 0
+    assert abs(out["efficiency"] - out["one_gpu_same_workload_ms"] / (ranks * out["ms_per_step"])) < 1e-3
     # the multi-GPU configuration BASELINE.json names for this many ranks, one frame strong-scaled over them, gather inside the timed region
     c4 = out["baseline_configs"]["C4"]
     assert c4["scaling"] == "strong" and c4["n_gpus"] == ranks and c4["assembled_equals_single_rank"] is True and c4["gather_in_timed_region"] is True
@@ -66,7 +71,8 @@ def test_bench_c5_path_with_eight_ranks_worth_of_arguments():
     ctx.barrier = lambda: torch.cuda.synchronize()
     ctx.max_over_ranks = ctx.sum_over_ranks = lambda x: x
     r = bench.Runner(ctx, wl, 3)
-    elapsed, rays, latency = r.timed(4, 1)
+    elapsed, rays, latency, blocks = r.timed(4, 1)
+    assert len(blocks) >= 1 and min(blocks) <= elapsed <= max(blocks)
     assert rays >= 4 * 480 * 272 * 16 and elapsed > 0 and latency > 0
     # tiles of 8 shards compose to the same frame
     whole = torch.zeros(wl.H, wl.W, 3, device="cuda")

@@ -351,9 +351,39 @@ def test_scene_l_at_640x480_counts_the_hidden_state_pixels(gpu_scenes, flat_scen
     print(f"scene l 640x480: {int(off.sum())} of 307200 pixels beyond 1/255 of the compiled reference (hidden-state pixels: at most 2)")
     assert int(off.sum()) <= 2
     assert abs(st["rays_nearest"] - int(g["rays_nearest"])) <= 4 and abs(st["rays_shadow"] - int(g["rays_shadow"])) <= 8
+    # The library reports that class itself: rt_stats.state_cases counts the exit searches that found no exit (objects.cpp:123-125), the only
+    # place where the reference reads state of earlier pixels.  The oracle counts the same event (oracle_state_cases) on the same ray trees.
+    oracle.state_cases(reset=True)
+    oracle.render(fs, cam, 640, 480, seed=1, threads=8)
+    want_cases = oracle.state_cases(reset=True)
+    print(f"scene l 640x480: {st['state_cases']} failed exit searches on the device, {want_cases} in the oracle")
+    assert st["state_cases"] == want_cases and want_cases >= int(off.sum())
     s = primary_targets_np(cam, 640, 480)
     r = sc.intersect_batch(np.zeros((640 * 480, 3), np.float32), s)
     assert np.array_equal(r["id"].astype(np.int16), g["id"])
+
+
+@pytest.mark.parametrize("name", list("acgijk"))
+def test_bundled_scenes_at_640x480_vs_reference_dump(name, gpu_scenes, flat_scenes):
+    """C1 at its stated size: the bundled scenes at the reference's own 640x480 against the compiled reference's dumps
+    (tests/golden/ref_<scene>_640.npz: packed hit mask, ids as int16, 8-bit RGB, both ray counts).  Mask, ids and ray counts exact,
+    every pixel of the 8-bit frame within 1."""
+    import os
+    from conftest import GOLD
+    g = dict(np.load(os.path.join(GOLD, f"ref_{name}_640.npz")))
+    fs, sc = flat_scenes(name), gpu_scenes(name)
+    cam = rt.Camera(fs.fov, 640, 480)
+    img = sc.render(640, 480, camera=cam)
+    st = dict(sc.last_stats)
+    got = rt.quantize_rgb8(img)[::-1].reshape(-1, 3)          # back to row 0 = bottom, the dump's order
+    d8 = np.abs(got.astype(int) - g["rgb8"].astype(int)).max(axis=1)
+    print(f"scene {name} 640x480: {int((d8 > 0).sum())} of 307200 pixels differ in the 8-bit frame, max {int(d8.max())}")
+    assert int((d8 > 1).sum()) == 0
+    assert st["rays_nearest"] == int(g["rays_nearest"]) and st["rays_shadow"] == int(g["rays_shadow"])
+    s = primary_targets_np(cam, 640, 480)
+    r = sc.intersect_batch(np.zeros((640 * 480, 3), np.float32), s)
+    assert np.array_equal(r["id"].astype(np.int16), g["id"])
+    assert np.array_equal(np.packbits(r["hit"] != 0), g["hit"])
 
 
 def test_c5_full_size_4k_16spp_properties(tmp_path):

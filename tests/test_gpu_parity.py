@@ -83,8 +83,8 @@ def test_random_scene_vs_reference_dump(name, gpu_scenes, flat_scenes, golden):
 
 def test_c2_family_vs_reference_dump(gpu_scenes, golden):
     """The benchmark's workload family against the COMPILED REFERENCE: the C2 generator with 4 608 triangles at 160x90 from bench.py's
-    camera (tests/golden/ref_c2_48.npz).  Ids, t, ray counts exact; RGB within 1/255 except texels picked across a texel boundary on
-    the bump-mapped spheres (int(u*W) with u from atan2f / asinf, bump.cpp:14-23: device libm against glibc), counted."""
+    camera (tests/golden/ref_c2_48.npz).  Ids, t, ray counts exact; RGB within 1/255 on every pixel, the bump-mapped spheres included
+    (their texel index is int(u*W) with u from atan2f / asinf, bump.cpp:14-23: csrc/glibc_math.h restates glibc's versions)."""
     g = golden("c2_48")
     n = int(g["W"]) * int(g["H"])
     sc = gpu_scenes("c2_48")
@@ -94,7 +94,7 @@ def test_c2_family_vs_reference_dump(gpu_scenes, golden):
     assert sc.last_stats["rays_nearest"] == int(g["rays_nearest"]) and sc.last_stats["rays_shadow"] == int(g["rays_shadow"])
     d8 = np.abs(rgb8(r["rgb"]).astype(int) - rgb8(g["rgb"]).astype(int)).max(axis=1)
     print(f"{int((d8 > 1).sum())} of {n} pixels beyond 1/255, {int((d8 > 0).sum())} differ at all")
-    assert (d8 > 1).mean() < 2e-3
+    assert (d8 > 1).sum() == 0
     a = sc.shadow_batch(g["shd_p"], g["shd_l"])
     assert np.array_equal(a["lit"], g["shd_lit"].astype(np.uint8))
     lit = a["lit"] != 0
@@ -346,7 +346,12 @@ def test_reference_api_client_end_to_end(tmp_path):
     sc = rt.Scene(flat, 0)
     cam = rt.Camera(flat.fov, W, H)
     s = oracle.primary_targets(cam, W, H).reshape(H, W, 3)
-    assert f"Loading scene {name}" in out
+    # the three lines choose_scene prints (raytracer.cpp:122,138,142).  Their format is the compiled reference's own, observed on its
+    # bundled scenes (oracle/_ref/ref_driver l: "Setting fov to 17 degrees." / "Setting background colour to vec3(0.000000, 0.000000, 0.100000)"):
+    # operator<< of a double, and glm::to_string(vec3) = "vec3(%f, %f, %f)"
+    bg = np.asarray(flat.background, np.float32)
+    assert out.splitlines()[:3] == [f"Loading scene {name}", "Setting fov to 60 degrees.",
+                                    "Setting background colour to vec3(%f, %f, %f)" % tuple(float(v) for v in bg)], out.splitlines()[:3]
     head = out[:out.index("== pixel")].splitlines()[-1].split()
     assert float(head[1]) == flat.fov and np.allclose([float(v) for v in head[3:6]], flat.background)
     blocks = out.split("== pixel ")[1:]

@@ -105,6 +105,18 @@ def test_view_renders_what_rt_render_renders_and_click_narrates(gpu_scenes, flat
          + np.array(cam.c.up[:], f32) * f32(2 * ((H - y_top - 1 + f32(0.5)) / f32(H) - f32(0.5))))
     hit, rgb, narration = sc.trace_pick(np.array(cam.c.eye[:], f32), s)
     assert text.startswith("\n" + narration) and (("HIT @ ( " in text and "      colour = ( " in text) if hit else "MISS @ ( " in text) and text.endswith("\n\n")
+    # a move key and then a click WITHOUT a frame in between: mouse() -> s(x, y) and trace(eye, ...) read the global eye, which `w` has
+    # already moved, together with the facing / camera_right / camera_up of the frame still on screen (q1.cpp:51-53, 189-191, 251-259)
+    v.key("w")
+    eye2 = v.state()["eye"].astype(f32)
+    assert not np.array_equal(eye2, np.array(cam.c.eye[:], f32))
+    text2 = v.click(x, y_top)
+    s2 = (eye2 + np.array(cam.c.facing[:], f32)
+          + np.array(cam.c.right[:], f32) * f32(2 * ((x + f32(0.5)) / f32(W) - f32(0.5)))
+          + np.array(cam.c.up[:], f32) * f32(2 * ((H - y_top - 1 + f32(0.5)) / f32(H) - f32(0.5))))
+    hit2, rgb2, narration2 = sc.trace_pick(eye2, s2)
+    want_at = ("HIT @ ( " if hit2 else "MISS @ ( ") + ",".join("%g" % c for c in s2) + " )\n"
+    assert text2.startswith("\n" + narration2) and want_at in text2, (text2, want_at)
     v.close()
     # the scripted session: frames as BMPs, the sixteen sweeps of the first one, the print-outs of p and l
     scenes_dir = tmp_path / "scenes"

@@ -36,10 +36,17 @@ def static_call(sc, e, d):
     oid = torch.full((max(n, 1),), 12345, dtype=torch.int32, device="cuda")
     t = torch.full((max(n, 1),), -3.0, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
+    # free device memory as the DRIVER counts it (hipMemGetInfo): torch's own statistics only see torch's caching allocator, a hipMalloc
+    # inside the library would pass them unnoticed.  (The first call on a handle loads its kernels, which may take memory: the
+    # comparison is made from the second call on; the graph-capture test below shows the same thing another way.)
+    warm = getattr(sc, "_static_warm", False)
+    before = torch.cuda.mem_get_info()[0]
     sc.intersect_batch_static(de.data_ptr(), dd.data_ptr(), n, hit.data_ptr(), oid.data_ptr(), t.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    assert torch.cuda.memory_allocated() == before
+    after = torch.cuda.mem_get_info()[0]
+    if warm:
+        assert after == before, f"free device memory went from {before} to {after} across the call"
+    sc._static_warm = True
     return hit.cpu().numpy()[:n], oid.cpu().numpy()[:n], t.cpu().numpy()[:n]
 
 
@@ -84,3 +91,49 @@ def test_static_entry_point_limits(gpu_scenes, flat_scenes):
     sc.intersect_batch_static(de.data_ptr(), dd.data_ptr(), 1000, 0, out.data_ptr(), 0)
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy()[:1000], sc.intersect_batch(e[:1000], d[:1000])["id"])
+
+
+def test_static_entry_point_under_graph_capture(gpu_scenes, flat_scenes):
+    """The call captured into a HIP graph (torch.cuda.graph: global capture mode, in which an allocating or synchronising runtime call
+    made by the capturing thread fails the capture), replayed twice -- the second time on other rays written into the same buffers --
+    and compared with rt_intersect_batch.  A capture with no ordinary call before it on the handle is refused."""
+    import raytracer_amd as rt
+    flat = flat_scenes("i")
+    sc = rt.Scene(flat, 0)                                  # a fresh handle: nothing has run on it yet
+    n = 20000
+    e1, d1 = rays_for(flat, n, 11)
+    e2, d2 = rays_for(flat, n, 12)
+    de, dd = torch.from_numpy(e1).cuda(), torch.from_numpy(d1).cuda()
+    hit = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+    oid = torch.full((n,), 12345, dtype=torch.int32, device="cuda")
+    t = torch.full((n,), -3.0, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    # (1) cold handle: refused, and the refusal leaves the capture intact (nothing was recorded, nothing illegal was called)
+    g0 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g0, stream=side):
+        with pytest.raises(RtError) as err:
+            sc.intersect_batch_static(de.data_ptr(), dd.data_ptr(), n, hit.data_ptr(), oid.data_ptr(), t.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        hit.add_(0)                                         # (an empty capture is not worth instantiating)
+    assert err.value.code == capi.RT_EINVAL and "outside the capture" in str(err.value)
+    # (2) one ordinary call, then the capture
+    sc.intersect_batch_static(de.data_ptr(), dd.data_ptr(), n, hit.data_ptr(), oid.data_ptr(), t.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    hit.fill_(7); oid.fill_(12345); t.fill_(-3.0)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        sc.intersect_batch_static(de.data_ptr(), dd.data_ptr(), n, hit.data_ptr(), oid.data_ptr(), t.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(hit[0]) == 7 and int(oid[0]) == 12345        # captured, not executed
+    for e, d in ((e1, d1), (e2, d2)):
+        de.copy_(torch.from_numpy(e)); dd.copy_(torch.from_numpy(d))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        ref = sc.intersect_batch(e, d)
+        assert np.array_equal(hit.cpu().numpy(), ref["hit"]) and np.array_equal(oid.cpu().numpy(), ref["id"])
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), ref["t"].view(np.uint32))
+        assert int(ref["hit"].sum()) > 100
+    del g, g0
+    sc.close()

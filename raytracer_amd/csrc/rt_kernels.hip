@@ -628,54 +628,74 @@ __device__ __forceinline__ void packetTri(const DevScene& S, Trav& T, bool inSub
 // reference's boxes nest exactly (min / max over subsets of the same primitives), so a ray that passes the inner box with the
 // reference's arithmetic would have passed every box around it.  Layout (rt_kernels.h): 128 B = two 64 B slots of a 1 KB treelet.
 // ---------------------------------------------------------------------------------------------------------
-struct QuadStep {
-	int32_t c[4];               // child references (wave-uniform); RT_QUAD_EMPTY = no such entry
-	uint32_t inf[4];            // what travels with each: treelet level (inner) or aux word (leaf)
-	unsigned long long m[4];    // lanes whose ray passed the entry's box
-};
-// Classifies the four boxes of the quad at `q` for this lane's ray.  KEYS: also the visiting keys of the nearest-hit walk -- entry
-// distance of the wave's first ray in the node (any order is correct; near first prunes more), index in the low two bits.
-template <bool KEYS>
-__device__ __forceinline__ void quadClassify(const float4* q, const Trav& T, f3 dExact, float tlimit, bool inSub, bool cons, uint32_t info, uint32_t firstLane, QuadStep& Q, uint32_t* keys) {
+// ---------------------------------------------------------------------------------------------------------
+// Box verdicts as lane masks (round 3).  Which rays of the packet are in the current node is a 64-bit mask in scalar registers,
+// not a flag per lane, and a box test yields two masks straight out of its two compares:
+//   H  the ray certainly passes the box within its limit,      N  it is not certain that it misses
+// so that "passed and in the node" is one s_and_b64 for 64 rays, and the stack, the pops and the choice of the next entry never touch
+// a vector register.  Per lane the test is  lo = max(tnear, 0),  u = min(tfar, limit),  visit <=> lo <= u : with the ray's start
+// folded into lo that is exactly the reference's  "tnear <= tfar, tfar >= 0, entry <= limit"  (entry = max(tnear, 0); its +-MAX_T
+// clamps are subsumed, every limit being <= MAX_T), and the zero and the limit ride in the min3 / max3 that combine the slabs.  The
+// multiply by the ray's 1/d is within 3 ulp of the reference's divide (boxClassify above), so  u - lo > m  with
+// m = 1e-6 (lo + |u|) + 1e-30  (8 ulp) is the reference's "visit" and  u - lo < -m  its "skip"; between the two (N and not H) nothing
+// is decided.  Lanes whose ray is NOT in the node get the limit -1: u <= -1 < 0 <= lo, never H; N is masked with the node's mask.
+//
+// Where "undecided" needs the reference's own arithmetic, and where not (round 3).  What the reference returns depends on the
+// verdicts of its LEAF boxes only: its boxes nest exactly and the slab arithmetic is monotone in the bounds (see "Quad nodes" above),
+// so a ray that passes a leaf's box has passed every box around it, and the set of leaves the reference visits is the set of leaves
+// whose own box it passes.  An inner entry may therefore be visited on N alone -- a superset costs a step, never a result -- and the
+// exact divide-based test (boxIntersect) runs only for undecided lanes of entries whose verdict is final: leaves of the reference's
+// tree, and entries that root the conservative sub-tree under a fat leaf (their box is that leaf's box).  Inside such sub-trees every
+// box is conservative anyway (undecided = visit).  Rays with a non-finite 1/d (`special`: 0 * inf = NaN, which v_min / v_max drop
+// silently) cannot trust H or N: in the reference's tree they take the exact test at every entry, in a sub-tree they visit.
+// ---------------------------------------------------------------------------------------------------------
+typedef unsigned long long u64;
+__device__ __forceinline__ bool laneOf(u64 mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }   // this lane's bit, as a condition code (no vector instruction)
+
+struct QuadHead { int32_t c[4]; uint32_t x[4]; };   // child references and aux words of a quad (wave-uniform)
+__device__ __forceinline__ QuadHead quadHead(const float4* q) {
 	const float4 q6 = q[6], q7 = q[7];
-	Q.c[0] = __builtin_amdgcn_readfirstlane(__float_as_int(q6.x)); Q.c[1] = __builtin_amdgcn_readfirstlane(__float_as_int(q6.y));
-	Q.c[2] = __builtin_amdgcn_readfirstlane(__float_as_int(q6.z)); Q.c[3] = __builtin_amdgcn_readfirstlane(__float_as_int(q6.w));
-	const uint32_t x[4] = { (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.x)), (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.y)),
-	                        (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.z)), (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.w)) };
-	const bool live = inSub && !T.special;
-	const bool odd = inSub && T.special;   // 1/d not finite: every box goes to the exact test
-#pragma unroll
-	for (int pair = 0; pair < 2; pair++) {   // two boxes at a time: three 16 B words hold a pair
-		const bool v0 = Q.c[2 * pair] != RT_QUAD_EMPTY, v1 = Q.c[2 * pair + 1] != RT_QUAD_EMPTY;   // (wave-uniform; applied to the lane masks below)
-		if (pair == 1 && !v0) {   // a quad of two entries (entries fill from the front): nothing in the second pair
-			Q.m[2] = 0; Q.m[3] = 0;
-			if (KEYS) { keys[2] = 0xffffffffu; keys[3] = 0xffffffffu; }
-			continue;
-		}
-		const float4 a = q[3 * pair], b = q[3 * pair + 1], c = q[3 * pair + 2];
-		const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
-		const float b1[6] = { b.z, b.w, c.x, c.y, c.z, c.w };
-		float t0, t1;
-		bool h0, h1, a0, a1;
-		boxClassifyFlat(b0, T.e, T.inv, tlimit, t0, h0, a0);
-		boxClassifyFlat(b1, T.e, T.inv, tlimit, t1, h1, a1);
-		h0 = h0 && live; h1 = h1 && live;
-		a0 = (a0 && inSub) || odd; a1 = (a1 && inSub) || odd;
-		if (cons) { h0 = h0 || a0; h1 = h1 || a1; }   // too close to call = visit
-		else if (__ballot(a0 || a1) != 0) {   // too close to call somewhere in the wave (rare): the reference's own arithmetic decides
-			// KEYS = the nearest-hit walk, whose limit is the best hit so far: there a box this close to the limit is visited (see travRound)
-			if (a0 && v0) { const float t = boxIntersect(b0, T.e, dExact, false); h0 = !(t < 0 || (!KEYS && t > tlimit)); }
-			if (a1 && v1) { const float t = boxIntersect(b1, T.e, dExact, false); h1 = !(t < 0 || (!KEYS && t > tlimit)); }
-		}
-		Q.m[2 * pair] = v0 ? __ballot(h0) : 0ull; Q.m[2 * pair + 1] = v1 ? __ballot(h1) : 0ull;
-		if (KEYS) {
-			const uint32_t k0 = __float_as_uint(fmaxf(t0, 0.0f)), k1 = __float_as_uint(fmaxf(t1, 0.0f));
-			keys[2 * pair] = Q.m[2 * pair] ? (((uint32_t)__builtin_amdgcn_readlane((int)k0, (int)firstLane) & ~3u) | (uint32_t)(2 * pair)) : 0xffffffffu;
-			keys[2 * pair + 1] = Q.m[2 * pair + 1] ? (((uint32_t)__builtin_amdgcn_readlane((int)k1, (int)firstLane) & ~3u) | (uint32_t)(2 * pair + 1)) : 0xffffffffu;
-		}
-	}
-#pragma unroll
-	for (int i = 0; i < 4; i++) Q.inf[i] = Q.c[i] < 0 ? x[i] : info + x[i];   // inner entry: aux = 1 if it roots another treelet (one level further down)
+	QuadHead h;
+	h.c[0] = __builtin_amdgcn_readfirstlane(__float_as_int(q6.x)); h.c[1] = __builtin_amdgcn_readfirstlane(__float_as_int(q6.y));
+	h.c[2] = __builtin_amdgcn_readfirstlane(__float_as_int(q6.z)); h.c[3] = __builtin_amdgcn_readfirstlane(__float_as_int(q6.w));
+	h.x[0] = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.x)); h.x[1] = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.y));
+	h.x[2] = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.z)); h.x[3] = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.w));
+	return h;
+}
+// is the verdict on this entry's box final (see above)?  `cons`: the quad itself belongs to a conservative sub-tree
+__device__ __forceinline__ bool entryIsFinal(int32_t c, bool cons) { return !cons && (c < 0 || ((uint32_t)c & RT_TREELET_CONS) != 0u); }
+
+// the slab differences of a pair of boxes (three 16 B words of a quad) from an origin: shared by every ray that starts there
+struct PairDiff { v2f_ x0, y0, z0, x1, y1, z1; };
+__device__ __forceinline__ PairDiff pairDiff(const float4& a, const float4& b, const float4& c, const f3& e) {
+	PairDiff D;
+	D.x0 = (v2f_){ a.x, a.y } - e.x; D.y0 = (v2f_){ a.z, a.w } - e.y; D.z0 = (v2f_){ b.x, b.y } - e.z;
+	D.x1 = (v2f_){ b.z, b.w } - e.x; D.y1 = (v2f_){ c.x, c.y } - e.y; D.z1 = (v2f_){ c.z, c.w } - e.z;
+	return D;
+}
+// verdict masks of the two boxes for one ray (direction 1/d = inv, limit tl: -1 in lanes that are not in the node); lo = max(tnear, 0)
+__device__ __forceinline__ void pairVerdict(const PairDiff& D, const f3& inv, float tl, u64& H0, u64& N0, u64& H1, u64& N1, float& lo0, float& lo1) {
+	const v2f_ tx0 = D.x0 * inv.x, ty0 = D.y0 * inv.y, tz0 = D.z0 * inv.z;
+	const v2f_ tx1 = D.x1 * inv.x, ty1 = D.y1 * inv.y, tz1 = D.z1 * inv.z;
+	lo0 = fmaxf(fmaxf(fminf(tx0.x, tx0.y), fminf(ty0.x, ty0.y)), fmaxf(fminf(tz0.x, tz0.y), 0.0f));
+	lo1 = fmaxf(fmaxf(fminf(tx1.x, tx1.y), fminf(ty1.x, ty1.y)), fmaxf(fminf(tz1.x, tz1.y), 0.0f));
+	const float u0 = fminf(fminf(fmaxf(tx0.x, tx0.y), fmaxf(ty0.x, ty0.y)), fminf(fmaxf(tz0.x, tz0.y), tl));
+	const float u1 = fminf(fminf(fmaxf(tx1.x, tx1.y), fmaxf(ty1.x, ty1.y)), fminf(fmaxf(tz1.x, tz1.y), tl));
+	const v2f_ lo = { lo0, lo1 }, u = { u0, u1 };
+	const v2f_ g = u - lo;
+	const v2f_ au = { fabsf(u0), fabsf(u1) };
+	// (the margin itself need not match anything bit for bit: a fused multiply-add, packed for the two boxes)
+	const v2f_ m = __builtin_elementwise_fma((v2f_){ 1e-6f, 1e-6f }, lo + au, (v2f_){ 1e-30f, 1e-30f });
+	H0 = __ballot(g.x > m.x); N0 = __ballot(!(g.x < -m.x));
+	H1 = __ballot(g.y > m.y); N1 = __ballot(!(g.y < -m.y));
+}
+// the reference's own test (objects.cpp:11-44 as bvh.cpp:97-100 / 131-134 use it) for the lanes of `lanes`: the ones it lets through.
+// NEAREST: the limit is the best hit so far and a box this close to it is visited whatever the comparison says (see travRound).
+template <bool NEAREST>
+__device__ __forceinline__ u64 boxExact(const float* b, const f3& e, const f3& d, u64 lanes, float tlimit) {
+	bool ok = false;
+	if (laneOf(lanes)) { const float t = boxIntersect(b, e, d, false); ok = !(t < 0 || (!NEAREST && t > tlimit)); }
+	return __ballot(ok);
 }
 
 // `alive`: the lane holds a query.  T must come from travInit (T.cur == kEmpty: the lane's ray missed the root box).
@@ -688,8 +708,10 @@ template <bool ANYHIT, bool CSG, bool COUNT, bool DEFER = false>
 __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLds& L, Trav& T, bool alive, Tracer* trp = nullptr) {
 	static_assert(!DEFER || (ANYHIT && CSG), "deferred CSG leaves: shadow queries only");
 	const uint32_t lane = __lane_id();
-	bool inSub = alive && T.cur != kEmpty;   // this lane's ray passed the box of the current node
-	if (__ballot(inSub) == 0) return;
+	u64 in = __ballot(alive && T.cur != kEmpty);   // the lanes whose ray passed the box of the current node
+	if (in == 0) return;
+	const u64 special = __ballot(alive && T.special);
+	u64 lit = ~0ull;                               // ANYHIT: lanes whose ray has not met an opaque occluder yet
 	int32_t node = S.treelet_root;
 	uint32_t info = node < 0 ? S.treelet_root_aux : 0u;   // inner node: treelet level; leaf: aux
 	int sp = 0;
@@ -707,7 +729,7 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			TR(3, node & 15);
 #if RT_PROF
 			T.steps++;
-			{ const int act = __popcll(__ballot(inSub)); const int b = act <= 2 ? 0 : act <= 4 ? 1 : act <= 8 ? 2 : act <= 16 ? 3 : act <= 32 ? 4 : act <= 48 ? 5 : 6; if (trp) trp->hist[b]++; }
+			{ const int act = __popcll(in); const int b = act <= 2 ? 0 : act <= 4 ? 1 : act <= 8 ? 2 : act <= 16 ? 3 : act <= 32 ? 4 : act <= 48 ? 5 : 6; if (trp) trp->hist[b]++; }
 #endif
 			const bool cons = ((uint32_t)node & RT_TREELET_CONS) != 0u;   // a node of a sub-tree under a fat leaf: conservative box tests
 			const int32_t nidx = (int32_t)((uint32_t)node & (RT_TREELET_CONS - 1u));
@@ -719,35 +741,67 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 				TR(4, nidx >> 4);
 			}
 			TR(12, 0);
+			const float4* q = buf + (nidx & (RT_QUAD_SLOTS - 1)) * 4;
+			const QuadHead Q = quadHead(q);
 			const float tlimit = ANYHIT ? 1.0f : T.tmin;
-			const unsigned long long mIn = __ballot(inSub);
-			const uint32_t firstLane = (uint32_t)__ffsll((long long)mIn) - 1u;
-			QuadStep Q;
-			uint32_t key[4] = { 0, 1, 2, 3 };
-			quadClassify<!ANYHIT>(buf + (nidx & (RT_QUAD_SLOTS - 1)) * 4, T, T.d, tlimit, inSub, cons, info, firstLane, Q, key);
-			if (COUNT || RT_PROF) T.cntNodes += inSub ? 1u : 0u;
+			const float tl = laneOf(in) ? tlimit : -1.0f;
+			const uint32_t firstLane = (uint32_t)__ffsll((long long)in) - 1u;
+			const u64 spIn = special & in;
+			u64 m[4];
+			uint32_t key[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
+			if (COUNT || RT_PROF) T.cntNodes += laneOf(in) ? 1u : 0u;
 			if (COUNT) T.cntSteps++;
-			TR(5, __popcll(Q.m[0] | Q.m[1] | Q.m[2] | Q.m[3]));
+#pragma unroll
+			for (int pair = 0; pair < 2; pair++) {   // two boxes at a time: three 16 B words hold a pair
+				if (pair == 1 && Q.c[2] == RT_QUAD_EMPTY) { m[2] = 0; m[3] = 0; continue; }   // a quad of two entries (entries fill from the front)
+				const float4 a = q[3 * pair], b = q[3 * pair + 1], c = q[3 * pair + 2];
+				const PairDiff D = pairDiff(a, b, c, T.e);
+				u64 H0, N0, H1, N1;
+				float lo0, lo1;
+				pairVerdict(D, T.inv, tl, H0, N0, H1, N1, lo0, lo1);
+				const u64 valid1 = (pair == 1 && Q.c[3] == RT_QUAD_EMPTY) ? 0ull : ~0ull;   // (wave-uniform)
+				u64 v0 = N0 & in, v1 = N1 & in & valid1;
+				if (cons) { v0 |= spIn; v1 |= spIn & valid1; }   // too close to call = visit
+				else {
+					const u64 a0 = (entryIsFinal(Q.c[2 * pair], false) ? v0 & ~H0 : 0ull) | spIn;
+					const u64 a1 = ((entryIsFinal(Q.c[2 * pair + 1], false) ? v1 & ~H1 : 0ull) | spIn) & valid1;
+					if ((a0 | a1) != 0) {   // too close to call where it counts (rare): the reference's own arithmetic decides
+						const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
+						const float b1[6] = { b.z, b.w, c.x, c.y, c.z, c.w };
+						if (a0 != 0) v0 = (v0 & ~a0) | boxExact<!ANYHIT>(b0, T.e, T.d, a0, tlimit);
+						if (a1 != 0) v1 = (v1 & ~a1) | boxExact<!ANYHIT>(b1, T.e, T.d, a1, tlimit);
+					}
+				}
+				m[2 * pair] = v0; m[2 * pair + 1] = v1;
+				if (!ANYHIT) {   // visiting keys: the entry distance of the wave's first ray in the node (any order is correct; near first prunes more)
+					if (v0 != 0) key[2 * pair] = ((uint32_t)__builtin_amdgcn_readlane(__float_as_int(lo0), (int)firstLane) & ~3u) | (uint32_t)(2 * pair);
+					if (v1 != 0) key[2 * pair + 1] = ((uint32_t)__builtin_amdgcn_readlane(__float_as_int(lo1), (int)firstLane) & ~3u) | (uint32_t)(2 * pair + 1);
+				}
+			}
+			TR(5, __popcll(m[0] | m[1] | m[2] | m[3]));
 			// The entry to go on with: the nearest one for the wave's first ray (nearest-hit walk), the first one any ray passed (shadow
 			// rays: any order is correct).  The other entries that some ray passed wait on the stack.  Written out per case: the entry's
 			// words are in scalar registers, and picking them by a run-time index costs more instructions than the step's box tests.
 			// (sp < RT_PACKET_STACK_DEPTH always holds: rt_scene_upload refuses a tree that does not pass RT_PACKET_STACK_FITS, rt_kernels.h)
-#define RT_Q_PUSH(i) do { if (Q.m[i] != 0 && sp < RT_PACKET_STACK_DEPTH) { *reinterpret_cast<uint4*>(L.stack[sp]) = make_uint4((uint32_t)Q.c[i], (uint32_t)Q.m[i], (uint32_t)(Q.m[i] >> 32), Q.inf[i]); sp++; } } while (0)
-#define RT_Q_TAKE(i) do { node = Q.c[i]; info = Q.inf[i]; inSub = ((Q.m[i] >> lane) & 1ull) != 0; popNext = false; } while (0)
+#define RT_Q_INF(i) (Q.c[i] < 0 ? Q.x[i] : info + Q.x[i])   /* inner entry: aux = 1 if it roots another treelet (one level further down) */
+#define RT_Q_PUSH(i) do { if (m[i] != 0 && sp < RT_PACKET_STACK_DEPTH) { *reinterpret_cast<uint4*>(L.stack[sp]) = make_uint4((uint32_t)Q.c[i], (uint32_t)m[i], (uint32_t)(m[i] >> 32), RT_Q_INF(i)); sp++; } } while (0)
+#define RT_Q_TAKE(i) do { const uint32_t inf_ = RT_Q_INF(i); node = Q.c[i]; info = inf_; in = m[i]; popNext = false; } while (0)
 			uint32_t first;
 			if (!ANYHIT) {
 				const uint32_t k01 = key[0] < key[1] ? key[0] : key[1], k23 = key[2] < key[3] ? key[2] : key[3];
 				const uint32_t kmin = k01 < k23 ? k01 : k23;
 				first = kmin == 0xffffffffu ? 4u : kmin & 3u;
-			} else first = Q.m[0] ? 0u : Q.m[1] ? 1u : Q.m[2] ? 2u : Q.m[3] ? 3u : 4u;
+			} else first = m[0] ? 0u : m[1] ? 1u : m[2] ? 2u : m[3] ? 3u : 4u;
 			if (first == 0u) { RT_Q_PUSH(3); RT_Q_PUSH(2); RT_Q_PUSH(1); RT_Q_TAKE(0); }
 			else if (first == 1u) { RT_Q_PUSH(3); RT_Q_PUSH(2); if (!ANYHIT) RT_Q_PUSH(0); RT_Q_TAKE(1); }
 			else if (first == 2u) { RT_Q_PUSH(3); if (!ANYHIT) { RT_Q_PUSH(1); RT_Q_PUSH(0); } RT_Q_TAKE(2); }
 			else if (first == 3u) { if (!ANYHIT) { RT_Q_PUSH(2); RT_Q_PUSH(1); RT_Q_PUSH(0); } RT_Q_TAKE(3); }
+#undef RT_Q_INF
 #undef RT_Q_PUSH
 #undef RT_Q_TAKE
 			TR(6, sp);
 		} else if (info != RT_TREELET_NO_RUN) {   // leaf made of consecutive triangles: no leaf_prims indirection
+			const bool inSub = laneOf(in);
 			const bool longRun = (info >> 26) == 0u;   // external run in its long form: info = count, first triangle = first leaf entry
 			const uint32_t count = longRun ? info : info >> 26;
 			TR(7, count);
@@ -772,32 +826,35 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 					__builtin_amdgcn_wave_barrier();
 				}
 			}
+			if (ANYHIT) lit = __ballot(T.lit);
 			TR(8, 0);
 		} else {   // leaf: bvh.cpp:109-118 / 145-157 for the lanes whose ray passed this leaf's box
+			const bool inSub = laneOf(in);
 			int32_t at = ~node;
 			for (;;) {
 				const uint32_t entry = *(cuint32*)(uintptr_t)(S.leaf_prims + at);
 				if (DEFER && RT_PRIM_TYPE(entry & ~RT_PRIM_LAST) == RT_PRIM_CSG) {   // (wave-uniform)
-					const unsigned long long m = __ballot(inSub && T.lit);
-					if (m != 0 && nDeferred < RT_PACKET_STACK_DEPTH) {   // (always: DEFER variants are launched only when RT_PACKET_DEFER_FITS, rtk_shadow_area)
-						if (lane == 0) reinterpret_cast<uint4*>(L.stack[nDeferred])[1] = make_uint4(entry & ~RT_PRIM_LAST, (uint32_t)m, (uint32_t)(m >> 32), (uint32_t)at + 1u);
+					const u64 md = in & __ballot(T.lit);
+					if (md != 0 && nDeferred < RT_PACKET_STACK_DEPTH) {   // (always: DEFER variants are launched only when RT_PACKET_DEFER_FITS, rtk_shadow_area)
+						if (lane == 0) reinterpret_cast<uint4*>(L.stack[nDeferred])[1] = make_uint4(entry & ~RT_PRIM_LAST, (uint32_t)md, (uint32_t)(md >> 32), (uint32_t)at + 1u);
 						nDeferred++;
 					}
 				} else packetPrim<ANYHIT, CSG && !DEFER, COUNT>(S, T, inSub, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u);
 				if (entry & RT_PRIM_LAST) break;
 				at++;
 			}
+			if (ANYHIT) lit = __ballot(T.lit);
 		}
 		if (popNext) {
 			for (;;) {
 				if (sp == 0) { walking = false; break; }
 				sp--;
 				const uint4 entry = *reinterpret_cast<const uint4*>(L.stack[sp]);
-				const unsigned long long m = (unsigned long long)entry.y | ((unsigned long long)entry.z << 32);
-				node = (int32_t)entry.x;
-				info = entry.w;
-				inSub = ((m >> lane) & 1ull) != 0 && (!ANYHIT || T.lit);
-				if (__ballot(inSub) != 0) break;   // nobody left who wants this subtree (occluded lanes)
+				node = __builtin_amdgcn_readfirstlane((int)entry.x);
+				info = (uint32_t)__builtin_amdgcn_readfirstlane((int)entry.w);
+				in = (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)entry.y) | ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)entry.z) << 32);
+				if (ANYHIT) in &= lit;
+				if (in != 0) break;   // nobody left who wants this subtree (occluded lanes)
 			}
 		}
 	}
@@ -805,26 +862,28 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 		for (int i = 0; i < nDeferred; i++) {
 			const uint4 en = reinterpret_cast<const uint4*>(L.stack[i])[1];
 			const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.x);
-			const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)en.y) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)en.z) << 32);
+			const u64 md = (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)en.y) | ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)en.z) << 32);
 			const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.w);
-			const bool in = ((m >> lane) & 1ull) != 0 && T.lit;
-			if (__ballot(in) == 0) continue;
-			packetPrim<ANYHIT, CSG, COUNT>(S, T, in, ref, key);
+			const bool inD = laneOf(md) && T.lit;
+			if (__ballot(inD) == 0) continue;
+			packetPrim<ANYHIT, CSG, COUNT>(S, T, inD, ref, key);
 		}
 	}
 }
 
 // Two shadow rays per lane: the rays from one surface point towards two lights.  Both start inside the same leaves, so
 // the nodes whose boxes contain the point -- most of what a shadow ray out of a height field visits -- are visited by
-// both, and a step's fixed cost (node fetch, ballots, stack, branches: ~100 of its ~125 instructions) is paid once for the
-// two.  Each ray keeps its own lane masks; every lane still applies the reference's tests to exactly the nodes and
+// both, and a step's fixed cost (node fetch, stack, branches) is paid once for the two, as are the slab differences (same
+// origin).  Each ray keeps its own lane masks; every lane still applies the reference's tests to exactly the
 // primitives its own walk of that ray would reach.  Any-hit only (no visiting order to respect).  A and B hold the same
 // origin.
 template <bool CSG, bool COUNT>
 __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketLds& L, Trav& A, Trav& B, bool aliveA, bool aliveB) {
 	const uint32_t lane = __lane_id();
-	bool inA = aliveA && A.cur != kEmpty, inB = aliveB && B.cur != kEmpty;
-	if (__ballot(inA || inB) == 0) return;
+	u64 inA = __ballot(aliveA && A.cur != kEmpty), inB = __ballot(aliveB && B.cur != kEmpty);
+	if ((inA | inB) == 0) return;
+	const u64 specialA = __ballot(aliveA && A.special), specialB = __ballot(aliveB && B.special);
+	u64 litA = ~0ull, litB = ~0ull;
 	int32_t node = S.treelet_root;
 	uint32_t info = node < 0 ? S.treelet_root_aux : 0u;
 	int sp = 0;
@@ -843,47 +902,45 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 				__builtin_amdgcn_wave_barrier();
 			}
 			const float4* q = buf + (nidx & (RT_QUAD_SLOTS - 1)) * 4;
-			const float4 q6 = q[6], q7 = q[7];
-			const int32_t c[4] = { __builtin_amdgcn_readfirstlane(__float_as_int(q6.x)), __builtin_amdgcn_readfirstlane(__float_as_int(q6.y)),
-			                       __builtin_amdgcn_readfirstlane(__float_as_int(q6.z)), __builtin_amdgcn_readfirstlane(__float_as_int(q6.w)) };
-			const uint32_t x[4] = { (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.x)), (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.y)),
-			                        (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.z)), (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(q7.w)) };
-			unsigned long long mA[4], mB[4];
-			if (COUNT) { A.cntNodes += inA ? 1u : 0u; B.cntNodes += inB ? 1u : 0u; A.cntSteps++; }
-			const bool liveA = inA && !A.special, liveB = inB && !B.special;
-			const bool oddA = inA && A.special, oddB = inB && B.special;
+			const QuadHead Q = quadHead(q);
+			const float tlA = laneOf(inA) ? 1.0f : -1.0f, tlB = laneOf(inB) ? 1.0f : -1.0f;
+			const u64 spA = specialA & inA, spB = specialB & inB;
+			u64 mA[4], mB[4];
+			if (COUNT) { A.cntNodes += laneOf(inA) ? 1u : 0u; B.cntNodes += laneOf(inB) ? 1u : 0u; A.cntSteps++; }
 #pragma unroll
 			for (int pair = 0; pair < 2; pair++) {
-				const bool v0 = c[2 * pair] != RT_QUAD_EMPTY, v1 = c[2 * pair + 1] != RT_QUAD_EMPTY;   // (wave-uniform; applied to the lane masks)
-				if (pair == 1 && !v0) { mA[2] = mA[3] = mB[2] = mB[3] = 0; continue; }   // a quad of two entries: nothing in the second pair
+				if (pair == 1 && Q.c[2] == RT_QUAD_EMPTY) { mA[2] = mA[3] = mB[2] = mB[3] = 0; continue; }   // a quad of two entries: nothing in the second pair
 				const float4 a = q[3 * pair], b = q[3 * pair + 1], cc = q[3 * pair + 2];
-				const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
-				const float b1[6] = { b.z, b.w, cc.x, cc.y, cc.z, cc.w };
-				float t;
-				bool h0A, h1A, h0B, h1B, a0A, a1A, a0B, a1B;
-				boxClassifyFlat(b0, A.e, A.inv, 1.0f, t, h0A, a0A);
-				boxClassifyFlat(b1, A.e, A.inv, 1.0f, t, h1A, a1A);
-				boxClassifyFlat(b0, A.e, B.inv, 1.0f, t, h0B, a0B);
-				boxClassifyFlat(b1, A.e, B.inv, 1.0f, t, h1B, a1B);
-				h0A = h0A && liveA; h1A = h1A && liveA; h0B = h0B && liveB; h1B = h1B && liveB;
-				a0A = (a0A && inA) || oddA; a1A = (a1A && inA) || oddA; a0B = (a0B && inB) || oddB; a1B = (a1B && inB) || oddB;
-				if (cons) { h0A = h0A || a0A; h1A = h1A || a1A; h0B = h0B || a0B; h1B = h1B || a1B; }
-				else if (__ballot(a0A || a1A || a0B || a1B) != 0) {   // too close to call somewhere (rare): the reference's own arithmetic decides
-					A.d = coldLd3(L.cold, COLD_DA); B.d = coldLd3(L.cold, COLD_DB);
-					if (a0A && v0) { const float tt = boxIntersect(b0, A.e, A.d, false); h0A = !(tt < 0 || tt > 1.0f); }
-					if (a1A && v1) { const float tt = boxIntersect(b1, A.e, A.d, false); h1A = !(tt < 0 || tt > 1.0f); }
-					if (a0B && v0) { const float tt = boxIntersect(b0, A.e, B.d, false); h0B = !(tt < 0 || tt > 1.0f); }
-					if (a1B && v1) { const float tt = boxIntersect(b1, A.e, B.d, false); h1B = !(tt < 0 || tt > 1.0f); }
+				const PairDiff D = pairDiff(a, b, cc, A.e);
+				u64 H0A, N0A, H1A, N1A, H0B, N0B, H1B, N1B;
+				float lo0, lo1;
+				pairVerdict(D, A.inv, tlA, H0A, N0A, H1A, N1A, lo0, lo1);
+				pairVerdict(D, B.inv, tlB, H0B, N0B, H1B, N1B, lo0, lo1);
+				const u64 valid1 = (pair == 1 && Q.c[3] == RT_QUAD_EMPTY) ? 0ull : ~0ull;   // (wave-uniform)
+				u64 v0A = N0A & inA, v1A = N1A & inA & valid1, v0B = N0B & inB, v1B = N1B & inB & valid1;
+				if (cons) { v0A |= spA; v1A |= spA & valid1; v0B |= spB; v1B |= spB & valid1; }   // too close to call = visit
+				else {
+					const bool f0 = entryIsFinal(Q.c[2 * pair], false), f1 = entryIsFinal(Q.c[2 * pair + 1], false);
+					const u64 a0A = (f0 ? v0A & ~H0A : 0ull) | spA, a0B = (f0 ? v0B & ~H0B : 0ull) | spB;
+					const u64 a1A = ((f1 ? v1A & ~H1A : 0ull) | spA) & valid1, a1B = ((f1 ? v1B & ~H1B : 0ull) | spB) & valid1;
+					if ((a0A | a0B | a1A | a1B) != 0) {   // too close to call where it counts (rare): the reference's own arithmetic decides
+						const f3 dA = coldLd3(L.cold, COLD_DA), dB = coldLd3(L.cold, COLD_DB);
+						const float b0[6] = { a.x, a.y, a.z, a.w, b.x, b.y };
+						const float b1[6] = { b.z, b.w, cc.x, cc.y, cc.z, cc.w };
+						if (a0A != 0) v0A = (v0A & ~a0A) | boxExact<false>(b0, A.e, dA, a0A, 1.0f);
+						if (a1A != 0) v1A = (v1A & ~a1A) | boxExact<false>(b1, A.e, dA, a1A, 1.0f);
+						if (a0B != 0) v0B = (v0B & ~a0B) | boxExact<false>(b0, A.e, dB, a0B, 1.0f);
+						if (a1B != 0) v1B = (v1B & ~a1B) | boxExact<false>(b1, A.e, dB, a1B, 1.0f);
+					}
 				}
-				mA[2 * pair] = v0 ? __ballot(h0A) : 0ull; mA[2 * pair + 1] = v1 ? __ballot(h1A) : 0ull;
-				mB[2 * pair] = v0 ? __ballot(h0B) : 0ull; mB[2 * pair + 1] = v1 ? __ballot(h1B) : 0ull;
+				mA[2 * pair] = v0A; mA[2 * pair + 1] = v1A; mB[2 * pair] = v0B; mB[2 * pair + 1] = v1B;
 			}
 			// the first entry any ray passed is walked next, the others wait on the stack (any order is correct for shadow rays); written
 			// out per case, see packetTraverse
-#define RT_Q_INF(i) (c[i] < 0 ? x[i] : info + x[i])
-#define RT_Q_PUSH(i) do { if ((mA[i] | mB[i]) != 0 && sp < RT_PACKET_STACK_DEPTH) { stack[2 * sp] = make_uint4((uint32_t)c[i], RT_Q_INF(i), 0u, 0u); \
+#define RT_Q_INF(i) (Q.c[i] < 0 ? Q.x[i] : info + Q.x[i])
+#define RT_Q_PUSH(i) do { if ((mA[i] | mB[i]) != 0 && sp < RT_PACKET_STACK_DEPTH) { stack[2 * sp] = make_uint4((uint32_t)Q.c[i], RT_Q_INF(i), 0u, 0u); \
 				stack[2 * sp + 1] = make_uint4((uint32_t)mA[i], (uint32_t)(mA[i] >> 32), (uint32_t)mB[i], (uint32_t)(mB[i] >> 32)); sp++; } } while (0)
-#define RT_Q_TAKE(i) do { const uint32_t inf_ = RT_Q_INF(i); node = c[i]; info = inf_; inA = ((mA[i] >> lane) & 1ull) != 0; inB = ((mB[i] >> lane) & 1ull) != 0; popNext = false; } while (0)
+#define RT_Q_TAKE(i) do { const uint32_t inf_ = RT_Q_INF(i); node = Q.c[i]; info = inf_; inA = mA[i]; inB = mB[i]; popNext = false; } while (0)
 			if ((mA[0] | mB[0]) != 0) { RT_Q_PUSH(3); RT_Q_PUSH(2); RT_Q_PUSH(1); RT_Q_TAKE(0); }
 			else if ((mA[1] | mB[1]) != 0) { RT_Q_PUSH(3); RT_Q_PUSH(2); RT_Q_TAKE(1); }
 			else if ((mA[2] | mB[2]) != 0) { RT_Q_PUSH(3); RT_Q_TAKE(2); }
@@ -892,6 +949,7 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 #undef RT_Q_PUSH
 #undef RT_Q_TAKE
 		} else if (info != RT_TREELET_NO_RUN) {
+			const bool la = laneOf(inA), lb = laneOf(inB);
 			const bool longRun = (info >> 26) == 0u;
 			const uint32_t count = longRun ? info : info >> 26;
 			const uint32_t key0 = (uint32_t)~node + 1u;
@@ -901,8 +959,8 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 				const float4* q = L.level((info >> RT_QUAD_SLOT_BITS) & 15u) + (info & (RT_QUAD_SLOTS - 1u)) * 4u;
 				for (uint32_t k = 0; k < count; k++, q += 4) {
 					const float4 a = q[0], b = q[1], c = q[2], d = q[3];
-					packetTri<true, COUNT>(S, A, inA, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), __float_as_uint(d.w), L.cold + COLD_SHA * 64);
-					packetTri<true, COUNT>(S, B, inB, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), __float_as_uint(d.w), L.cold + COLD_SHB * 64);
+					packetTri<true, COUNT>(S, A, la, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), __float_as_uint(d.w), L.cold + COLD_SHA * 64);
+					packetTri<true, COUNT>(S, B, lb, a, b, c, __float_as_uint(d.z), __float_as_int(d.y), __float_as_uint(d.w), L.cold + COLD_SHB * 64);
 				}
 			} else {
 				const uint32_t first = longRun ? (uint32_t)~node : info & (RT_TREELET_EMBED - 1u);
@@ -913,34 +971,36 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 					__builtin_amdgcn_wave_barrier();
 					for (uint32_t k = 0; k < nb; k++) {
 						const float4 a = buf[4 * k], b = buf[4 * k + 1], c = buf[4 * k + 2], d = buf[4 * k + 3];
-						packetTri<true, COUNT>(S, A, inA, a, b, c, first + k0 + k, __float_as_int(d.y), key0 + k0 + k, L.cold + COLD_SHA * 64);
-						packetTri<true, COUNT>(S, B, inB, a, b, c, first + k0 + k, __float_as_int(d.y), key0 + k0 + k, L.cold + COLD_SHB * 64);
+						packetTri<true, COUNT>(S, A, la, a, b, c, first + k0 + k, __float_as_int(d.y), key0 + k0 + k, L.cold + COLD_SHA * 64);
+						packetTri<true, COUNT>(S, B, lb, a, b, c, first + k0 + k, __float_as_int(d.y), key0 + k0 + k, L.cold + COLD_SHB * 64);
 					}
 					__builtin_amdgcn_wave_barrier();
 				}
 			}
+			litA = __ballot(A.lit); litB = __ballot(B.lit);
 		} else {
+			const bool la = laneOf(inA), lb = laneOf(inB);
 			int32_t at = ~node;
 			A.d = coldLd3(L.cold, COLD_DA); B.d = coldLd3(L.cold, COLD_DB); A.len = L.cold[COLD_LENA * 64]; B.len = L.cold[COLD_LENB * 64];
 			for (;;) {
 				const uint32_t entry = *(cuint32*)(uintptr_t)(S.leaf_prims + at);
-				packetPrim<true, CSG, COUNT>(S, A, inA, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u, L.cold + COLD_SHA * 64);
-				packetPrim<true, CSG, COUNT>(S, B, inB, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u, L.cold + COLD_SHB * 64);
+				packetPrim<true, CSG, COUNT>(S, A, la, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u, L.cold + COLD_SHA * 64);
+				packetPrim<true, CSG, COUNT>(S, B, lb, entry & ~RT_PRIM_LAST, (uint32_t)at + 1u, L.cold + COLD_SHB * 64);
 				if (entry & RT_PRIM_LAST) break;
 				at++;
 			}
+			litA = __ballot(A.lit); litB = __ballot(B.lit);
 		}
 		if (popNext) {
 			for (;;) {
 				if (sp == 0) return;
 				sp--;
 				const uint4 e0 = stack[2 * sp], e1 = stack[2 * sp + 1];
-				const unsigned long long mA = (unsigned long long)e1.x | ((unsigned long long)e1.y << 32), mB = (unsigned long long)e1.z | ((unsigned long long)e1.w << 32);
-				node = (int32_t)e0.x;
-				info = e0.y;
-				inA = ((mA >> lane) & 1ull) != 0 && A.lit;
-				inB = ((mB >> lane) & 1ull) != 0 && B.lit;
-				if (__ballot(inA || inB) != 0) break;
+				node = __builtin_amdgcn_readfirstlane((int)e0.x);
+				info = (uint32_t)__builtin_amdgcn_readfirstlane((int)e0.y);
+				inA = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)e1.x) | ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)e1.y) << 32)) & litA;
+				inB = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)e1.z) | ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)e1.w) << 32)) & litB;
+				if ((inA | inB) != 0) break;
 			}
 		}
 	}

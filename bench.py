@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # 256 CUs x 4 SIMDs x 2.4 GHz / 2.  tools/ubench/valu_issue.hip measures 1.10e12 for v_mul_f32 and half that for packed f32 on the box.
 SIMDS, CLOCK_GHZ, VALU_ISSUE_CYCLES = 1024, 2.4, 2.0
 VALU_PEAK_GIPS = SIMDS * CLOCK_GHZ / VALU_ISSUE_CYCLES
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")
+PMC_FILE = os.environ.get("RT_PMC_FILE") or os.path.join(ROOT, "profiles", "r03_pmc_counters.json")   # (the override: tools/evidence_r03.sh, same box, same build)
 # algorithmic bytes per unit of traversal work (with this build's 64 B two-child node)
 NODE_BYTES, TRI_BYTES, RAY_QUEUE_BYTES, HIT_QUEUE_BYTES, SURF_BYTES = 64, 64, 44, 12, 84
 
@@ -244,7 +244,7 @@ def one_gpu_ms(ctx, wl, D, steps):
 
 
 def load_pmc():
-    """Counters of the final build's kernels (tools/pmc_r02.sh -> tools/pmc_summary.py): they cannot be read from inside this process,
+    """Counters of the final build's kernels (tools/evidence_r03.sh -> tools/config_roofline.py): they cannot be read from inside this process,
     so they come from the committed file -- and only if it was taken with these very sources."""
     from raytracer_amd import buildinfo
     try:
@@ -306,7 +306,10 @@ def roofline_block(runner, flat):
                     "traffic": traffic,
                     "hbm_achieved_gbs": round(traffic / (ms * 1e-3) / 1e9, 1) if traffic else None,
                     "hbm_frac": round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                    "counters_from": os.path.relpath(PMC_FILE, ROOT)})
+                    "l2_hit_rate": round(k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]), 4) if k.get("TCC_HIT_sum") is not None and (k.get("TCC_HIT_sum", 0) + k.get("TCC_MISS_sum", 0)) > 0 else None,
+                    # mean waves resident per SIMD over the launch (SQ_WAVE_CYCLES is in quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs)
+                    "mean_resident_waves_per_simd": round(wc * 4 / (k["GRBM_GUI_ACTIVE"] / 8) / SIMDS, 2) if wc and k.get("GRBM_GUI_ACTIVE") else None,
+                    "counters_from": os.path.relpath(os.path.abspath(PMC_FILE), ROOT)})
         # the whole step against the same two ceilings: every kernel's instructions and HBM bytes over the pipelined frame time
         out["_step_valu"] = sum(v.get("SQ_INSTS_VALU", 0) * v.get("launches_per_frame", 1) for v in kernels.values())
         out["_step_traffic"] = sum((v.get("traffic_bytes_per_launch") or 0) * v.get("launches_per_frame", 1) for v in kernels.values())
@@ -367,7 +370,7 @@ def main():
     ap.add_argument("--c4-samples", type=int, default=64)
     ap.add_argument("--c5-grid", type=int, default=1581, help="C5 height-field cells per side (1581 -> 4 999 122 triangles)")
     ap.add_argument("--config-steps", type=int, default=10, help="timed frames of the C4 / C5 runs")
-    ap.add_argument("--all-configs", action="store_true", help="N = 1: also time every BASELINE configuration with a CPU baseline (tools/bench_configs.py -> profiles/r02_configs.json)")
+    ap.add_argument("--all-configs", action="store_true", help="N = 1: also time every BASELINE configuration with a CPU baseline (tools/bench_configs.py -> profiles/r03_configs.json)")
     ap.add_argument("--save", default=None, help="write the last frame as a BMP (rank 0)")
     args = ap.parse_args()
 
@@ -474,7 +477,7 @@ def main():
     if args.all_configs and world == 1 and rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_configs
-        configs_file = bench_configs.run_all(os.path.join(ROOT, "profiles", "r02_configs.json"))
+        configs_file = bench_configs.run_all(os.path.join(ROOT, "profiles", "r03_configs.json"))
 
     if rank == 0:
         value = rays / elapsed / 1e6

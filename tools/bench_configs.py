@@ -10,7 +10,8 @@
 Per configuration: GPU ms per frame (frames in flight, and one frame alone), rays per frame, Mrays/s; the oracle restatement
 (bit-identical to the compiled reference on the bundled scenes) on one thread and on all threads, on a BOUNDED sample of the same
 workload -- the same scene and camera at a reduced resolution where the full frame would take more than a few seconds (it is a
-rate: rays per second of the same ray tree) -- and the ratio.  Writes profiles/r02_configs.json.
+rate: rays per second of the same ray tree) -- and the ratio.  Writes profiles/r03_configs.json; every configuration whose kernels have committed counters of this very build
+(profiles/r03_config_roofline.json, tools/config_roofline.py) carries a `roofline` block for the kernels that dominate its frame.
 Usage: python tools/bench_configs.py [out.json]      (CONFIGS=C1,C3 restricts; C5_GRID=500 shrinks C5 for a rehearsal)
 """
 import gzip
@@ -61,6 +62,28 @@ def run_all(out_path, log=print):
     only = [c for c in os.environ.get("CONFIGS", "").split(",") if c]
     c5_grid = int(os.environ.get("C5_GRID", "1581"))
     rows = []
+    # roofline blocks per configuration: counters of the kernels alone, only if they were taken with these very sources
+    from raytracer_amd import buildinfo
+    roof, roof_path = {}, os.environ.get("RT_CONFIG_ROOFLINE") or os.path.join(ROOT, "profiles", "r03_config_roofline.json")
+    try:
+        rdoc = json.load(open(roof_path))
+        if rdoc.get("source_sha") == buildinfo.source_sha():
+            roof = rdoc.get("configs", {})
+        else:
+            log(f"{roof_path} is for sources {rdoc.get('source_sha')}, this build is {buildinfo.source_sha()}: no roofline blocks")
+    except (OSError, ValueError):
+        log(f"no {roof_path}: no roofline blocks")
+
+    def roofline_of(name):
+        b = roof.get(name.split("-")[0])
+        if not b or name.startswith("C1"):
+            return None
+        keep = ("kernel", "share_of_kernel_time", "avg_launch_us", "valu_insts_per_launch", "frac_of_valu_issue", "salu_plus_branch_per_valu", "wave_wait_frac",
+                "hbm_bytes_per_launch", "hbm_frac", "l2_hit_rate", "mean_resident_waves_per_simd", "launches_in_trace")
+        ks = [{k: e.get(k) for k in keep} for e in b["kernels"] if e["share_of_kernel_time"] >= 0.05]
+        return {"bound": "valu_issue", "peak": "1228.8 G wave-instr/s (1024 SIMDs x 2.4 GHz / 2); HBM 8000 GB/s", "kernels_alone": True,
+                "dominant_kernel": b["dominant_kernel"], "frac": ks[0]["frac_of_valu_issue"] if ks else None, "kernels": ks,
+                "counters_from": os.path.relpath(os.path.abspath(roof_path), ROOT), "source_sha": buildinfo.source_sha()}
 
     def one(name, label, flat, W, H, aa=1, max_depth=16, eye=(0.0, 0.0, 0.0), rot_x=0.0, reps=5, cpu_scale=1, cpu_aa=None, cpu_threads_only=False):
         alone, piped, st = gpu_time(rt, torch, flat, W, H, (aa, aa), max_depth, eye, rot_x, reps)
@@ -91,7 +114,8 @@ def run_all(out_path, log=print):
                "cpu_mrays_s_1_thread": None if cpu1 is None else round(cpu1, 3), "cpu_mrays_s_all_threads": round(cpuN, 3), "cpu_threads": threads,
                "cpu_sample": f"{cw}x{ch}, {ca * ca} sample(s)/pixel, same scene, camera and depth limit ({nn + ns} rays in {dN:.2f} s on {threads} threads)",
                "gpu_over_cpu_all_threads": round(rays / piped / 1e6 / cpuN, 1),
-               "gpu_over_cpu_1_thread": None if cpu1 is None else round(rays / piped / 1e6 / cpu1, 1)}
+               "gpu_over_cpu_1_thread": None if cpu1 is None else round(rays / piped / 1e6 / cpu1, 1),
+               "roofline": roofline_of(name)}
         rows.append(row)
         log(f"{name}: GPU {row['gpu_ms_per_frame']} ms/frame ({row['gpu_single_frame_ms']} alone), {rays / 1e6:.2f} Mrays, {row['gpu_mrays_s']} Mrays/s; "
             f"CPU {row['cpu_mrays_s_1_thread']} / {row['cpu_mrays_s_all_threads']} Mrays/s (1 / {threads} threads); x{row['gpu_over_cpu_all_threads']}")
@@ -129,4 +153,4 @@ def run_all(out_path, log=print):
 
 
 if __name__ == "__main__":
-    run_all(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_configs.json"))
+    run_all(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_configs.json"))

@@ -119,6 +119,7 @@ struct rt_scene {
 	RtTexFix texFix(const Lane& ln) const { return RtTexFix{ texelFix ? ln.texRec : nullptr, texHeads, texCap, &ln.ctr->texrec_count }; }
 	uint32_t qcap = 0;
 	int maxBlocks = 2048;            // grid cap of the persistent kernels
+	RtSmallScene small;              // the scene's walk / shading arrays as one blob for k_level's LDS copy (small scenes only)
 	int maxBlocksPacketNear = 2048;  // ... of the nearest-hit packet kernel (see rt_scene_upload)
 	int maxBlocksPacketShadow = 2048;   // ... and of the shadow packet kernels (one light per packet / two)
 	int maxBlocksPacketShadow2 = 2048;
@@ -853,14 +854,21 @@ struct Run {
 				const uint32_t nb = (uint32_t)std::min<uint64_t>(bound, sc->qcap);
 				const uint32_t* nDev = lv == 0 ? nullptr : &L[lv - 1].next_count;
 				const bool packets = coherent(lv);
+				// deeper levels (incoherent rays): one launch walks, shades and lights a ray (k_level); level 0 and scenes that keep texel records
+				// go through the queues (RT_NO_FUSED_LEVELS: everything does -- read per call, the tests compare the two forms)
+				const bool fused = !packets && lv > 0 && !sc->texelFix && getenv("RT_NO_FUSED_LEVELS") == nullptr;
+				if (fused) rtk_level(st, sc->dev, sc->small, sc->hasCsg, ln->ray[cur], nb, nDev, ln->ray[cur ^ 1], ln->surfq, ln->transq, &L[lv], sc->accum, aaSq, maxDepth,
+				                     !shadows ? 0 : sc->areaLights.empty() ? 1 : 2, sc->pointLights, (uint32_t)sc->nPointLights);
+				else {
 				rtk_intersect(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketNear : sc->maxBlocks, ln->ray[cur], nb, ln->hitq, &L[lv], nDev);
 				rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, nb, ln->ray[cur ^ 1], ln->surfq, ln->transq, &L[lv], sc->accum, aaSq, maxDepth,
 				          shadows, lv == 0 ? src.outHit : nullptr, src.outId, src.outT, pick, sc->texFix(*ln), nDev);
+				}
 				if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, nb, ln->ray[cur ^ 1], &L[lv], &ln->ctr->state_cases, sc->accum, aaSq, maxDepth, pick);
 				seqOf[lv] = ++ln->reportSeq ? ln->reportSeq : ++ln->reportSeq;   // (never 0)
 				rtk_publish(st, &L[lv], sc->texelFix ? &ln->ctr->texrec_count : nullptr, sc->hasTransmissive ? &ln->ctr->state_cases : nullptr, ln->reportDev + lv, seqOf[lv]);
 				if (shadows) {
-					if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nb, sc->pointLights, sc->nPointLights, sc->accum, aaSq, &L[lv], true, sc->maxBlocksPacketShadow2);
+					if (sc->nPointLights && !fused) rtk_shadow_point(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nb, sc->pointLights, sc->nPointLights, sc->accum, aaSq, &L[lv], true, sc->maxBlocksPacketShadow2);
 					for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, sc->nCsg, false, ln->surfq, nb, al.first, al.second, seed, sc->accum, aaSq, &L[lv], true);
 				}
 				if (int rcL = launchesOk()) return rcL;
@@ -1115,6 +1123,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	if ((rc = sc->upload(s->texels, s->n_texel_bytes, &D.texels))) return fail(rc);
 	if ((rc = sc->upload(s->leaf_prims, s->n_leaf_prims, &D.leaf_prims))) return fail(rc);
 	const bool timing = getenv("RT_LOAD_TIMING") != nullptr;
+	size_t treeletBytes = 0; int treeDepth = 0;
 	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double tUp0 = now();
 	{
@@ -1143,6 +1152,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 		const rt_bvh_node* tl = nullptr;
 		if ((rc = sc->upload(treelets.data(), (int64_t)treelets.size(), &tl))) return fail(rc);
 		D.treelets = reinterpret_cast<const float4*>(tl);
+		treeletBytes = treelets.size() * sizeof(rt_bvh_node); treeDepth = aug.depth;
 		{	// the packet walks' form of the same tree
 			std::vector<rt_bvh_node> quads;
 			bool quadRuns = false;
@@ -1196,6 +1206,39 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	const int32_t* plDev = nullptr;
 	if ((rc = sc->upload(pl.data(), (int64_t)pl.size(), &plDev))) return fail(rc);
 	sc->pointLights = const_cast<int32_t*>(plDev);
+	{	// small scenes (every scene the reference ships): what the per-lane walks and the shading read, as one blob for k_level's LDS copy
+		struct Sec { int id; const void* dev; size_t bytes; };
+		const Sec secs[] = {
+			{ RT_SMALL_TREELETS, D.treelets, treeletBytes }, { RT_SMALL_LEAF_PRIMS, D.leaf_prims, (size_t)s->n_leaf_prims * sizeof(uint32_t) },
+			{ RT_SMALL_SPHERES, D.spheres, (size_t)s->n_spheres * sizeof(rt_sphere) }, { RT_SMALL_BOXES, D.boxes, (size_t)s->n_boxes * sizeof(rt_box) },
+			{ RT_SMALL_PLANES, D.planes, (size_t)s->n_planes * sizeof(rt_plane) }, { RT_SMALL_MATERIALS, D.materials, (size_t)s->n_materials * sizeof(rt_material) },
+			{ RT_SMALL_LIGHTS, D.lights, (size_t)s->n_lights * sizeof(rt_light) }, { RT_SMALL_CSGS, D.csgs, (size_t)s->n_csgs * sizeof(rt_csg) },
+			{ RT_SMALL_CSG_NODES, D.csg_nodes, (size_t)s->n_csg_nodes * sizeof(rt_csg_node) }, { RT_SMALL_LIGHT_LIST, plDev, pl.size() * sizeof(int32_t) },
+			{ RT_SMALL_TRIS, D.tris, (size_t)s->n_tris * sizeof(rt_tri) } };
+		const size_t stackRows = (size_t)std::max(2, treeDepth + 2), stackBytes = stackRows * RT_BLOCK * sizeof(int32_t);
+		auto pad16 = [](size_t b) { return (b + 15) / 16 * 16; };
+		size_t need = 0;
+		for (const Sec& e : secs) if (e.id != RT_SMALL_TRIS) need += pad16(e.bytes);
+		if (stackRows <= RT_STACK_DEPTH && stackBytes + need <= RT_SMALL_SCENE_LDS_BYTES && getenv("RT_NO_SMALL_SCENE_BLOB") == nullptr) {
+			const bool withTris = stackBytes + need + pad16((size_t)s->n_tris * sizeof(rt_tri)) <= RT_SMALL_SCENE_LDS_BYTES;
+			const size_t total = std::max<size_t>(16, need + (withTris ? pad16((size_t)s->n_tris * sizeof(rt_tri)) : 0));
+			void* blob = nullptr;
+			if (hipMalloc(&blob, total) != hipSuccess) { rt::set_error("hipMalloc failed (small-scene blob)"); return fail(RT_EHIP); }
+			sc->allocs.push_back(blob);
+			HIPCHK(hipMemset(blob, 0, total));
+			size_t at = 0;
+			for (const Sec& e : secs) {
+				if (e.id == RT_SMALL_TRIS && !withTris) { sc->small.off[e.id] = 0xffffffffu; continue; }
+				sc->small.off[e.id] = (uint32_t)at;
+				if (e.bytes) HIPCHK(hipMemcpy((char*)blob + at, e.dev, e.bytes, hipMemcpyDeviceToDevice));
+				at += pad16(e.bytes);
+			}
+			sc->small.blob = reinterpret_cast<const uint4*>(blob);
+			sc->small.bytes = (uint32_t)total;
+			sc->small.stackRows = (uint32_t)stackRows;
+			if (timing) fprintf(stderr, "[upload] small scene: %zu B blob + %zu B stack for k_level's LDS\n", total, stackBytes);
+		}
+	}
 
 	sc->qcap = std::max<uint32_t>(1024, envU32("RT_QUEUE_RAYS", 8u << 20));
 	sc->texCap = std::min<uint32_t>(sc->qcap, 2u << 20);

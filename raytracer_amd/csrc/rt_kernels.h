@@ -151,6 +151,21 @@ void rtk_transmit(hipStream_t st, const DevScene& S, bool csg, RtQueue tq, uint3
 void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue hq, uint32_t n, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
                uint32_t aaSq, int maxDepth, int wantSurfaces, uint8_t* outHit, int32_t* outId, float* outT, RtPick pick = RtPick{ nullptr, nullptr, 0 },
                RtTexFix tex = RtTexFix{ nullptr, nullptr, 0, nullptr }, const uint32_t* nDev = nullptr);
+// The arrays of a SMALL scene that the per-lane walks and the shading read, as one device blob (sections 16 B aligned) that k_level copies
+// into LDS: assembled by rt_scene_upload when blob + per-lane stack fit RT_SMALL_SCENE_LDS_BYTES.  blob == nullptr: the scene is not small.
+enum { RT_SMALL_TREELETS, RT_SMALL_LEAF_PRIMS, RT_SMALL_SPHERES, RT_SMALL_BOXES, RT_SMALL_PLANES, RT_SMALL_MATERIALS, RT_SMALL_LIGHTS, RT_SMALL_CSGS, RT_SMALL_CSG_NODES,
+       RT_SMALL_LIGHT_LIST, RT_SMALL_TRIS, RT_SMALL_SECTIONS };
+#define RT_SMALL_SCENE_LDS_BYTES (60u * 1024u)
+struct RtSmallScene {
+	const uint4* blob = nullptr;
+	uint32_t bytes = 0;          // of the blob (a multiple of 16)
+	uint32_t stackRows = 0;      // entries of the per-lane stack: the tree's depth + 2
+	uint32_t off[RT_SMALL_SECTIONS] = {};   // byte offsets of the sections; RT_SMALL_TRIS: 0xffffffff when the triangles did not fit (they stay in memory)
+};
+// a deeper level in one launch: nearest hits, shading, shadow rays towards the `nLights` point-type lights of lightList, appends (k_level);
+// surfaces: 0 no shadow-casting lights, 1 count the hits, 2 also write their surface records (area lights: k_shadow_area follows)
+void rtk_level(hipStream_t st, const DevScene& S, const RtSmallScene& small, bool csg, RtQueue rq, uint32_t n, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
+               uint32_t aaSq, int maxDepth, int surfaces, const int32_t* lightList, uint32_t nLights);
 // after the last level of a batch: the corrections for `count` records, then the lists and the record counter are emptied again
 void rtk_texel_fix(hipStream_t st, const DevScene& S, bool csg, RtTexFix tex, uint32_t count, RtCounters* ctr, RtAccum A, uint32_t aaSq, uint32_t seed, bool apply);
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,

@@ -1334,49 +1334,35 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 	return result;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// shade: everything Object::lightPoint does except the shadow rays
-// ---------------------------------------------------------------------------------------------------------
-// (the plain variant fits 64 VGPRs without spilling: 8 waves per SIMD, so that it shares a SIMD with whatever the other lanes run: +1 % on C2)
-// MULTI: several samples per pixel -- the accumulator atomics of neighbouring lanes are combined first (accumAddRows)
-template <bool CSG, bool PICK, bool TEXFIX, bool MULTI>
-__global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX || MULTI) ? 1 : 8) void k_shade(DevScene S, RtQueue rq, RtQueue hq, uint32_t nArg, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
-                                                  RtAccum A, uint32_t aaSq, int maxDepth, int wantSurfaces,
-                                                  uint8_t* outHit, int32_t* outId, float* outT, RtPick pick, RtTexFix tex) {
-	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-	const uint32_t n = deviceCount(nArg, nDev);
-	if (blockIdx.x * kBlock >= n) return;   // (workgroup-uniform: a launch sized by a bound leaves its surplus workgroups at once)
-	// every record is read at once (index clamped, result masked): one memory round trip instead of two
-	const uint32_t ic = i < n ? i : 0u;
-	uint32_t pixKey = qu(rq, RQ_PIX, ic), path = qu(rq, RQ_PATH, ic), prim = qu(hq, HQ_PRIM, ic);
-	f3 e = mk3(qf(rq, RQ_OX, ic), qf(rq, RQ_OY, ic), qf(rq, RQ_OZ, ic));
-	f3 d = mk3(qf(rq, RQ_DX, ic), qf(rq, RQ_DY, ic), qf(rq, RQ_DZ, ic));
-	f3 w = mk3(qf(rq, RQ_WR, ic), qf(rq, RQ_WG, ic), qf(rq, RQ_WB, ic));
-	float t = qf(hq, HQ_T, ic);
-	const bool live = i < n && pixKey != kInactive;
-	if (!live) { pixKey = 0; path = 1; prim = RT_NO_HIT; e = mk3(0, 0, 0); d = mk3(0, 0, 1); w = mk3(0, 0, 0); t = 0; }
-	const uint32_t pixel = pixKey / aaSq;
-	const bool hit = live && prim != RT_NO_HIT;
-	const f3 background = ld3(S.background);
-	if (live && path == 1u && outHit) {   // first-level results for rt_trace_batch
-		outHit[pixKey] = hit;
-		if (outId) outId[pixKey] = hit ? primId(S, prim) : -1;
-		if (outT) outT[pixKey] = hit ? t : 0.0f;
-	}
+// What Object::lightPoint (objects.cpp:54-105) does for one ray apart from tracing its children and its shadow rays: the background a
+// miss fetches, normal, material (texel), ambient term, the reflected child and the request for the transmitted one.  Shared by
+// k_shade and k_level; forced inline, the outputs are the callers' registers.
+struct ShadeOut {
+	f3 own, beyond; bool hasOwn, hasBeyond;             // what the ray adds to its pixel by itself (MULTI: sent by the caller)
+	bool wantR, wantX, wantS, wantTex; uint32_t texTri; float refraction;
+	f3 p, N, V, rO, rD, rW, tW, wl; float kd[3], ks[3], shininess;
+};
+template <bool CSG, bool PICK, bool TEXFIX, bool MULTI, class TagOf>
+__device__ __forceinline__ void shadeRay(const DevScene& S, bool live, bool hit, uint32_t prim, float t, f3 e, f3 d, f3 w, uint32_t pixel, uint32_t path, f3 background,
+                                         const RtAccum& A, int maxDepth, int wantSurfaces, const RtPick& pick, TagOf tagOf, ShadeOut& o) {
+	f3& own = o.own; f3& beyond = o.beyond; bool& hasOwn = o.hasOwn; bool& hasBeyond = o.hasBeyond;
+	bool& wantR = o.wantR; bool& wantX = o.wantX; bool& wantS = o.wantS; bool& wantTex = o.wantTex; uint32_t& texTri = o.texTri; float& refraction = o.refraction;
+	f3& p = o.p; f3& N = o.N; f3& V = o.V; f3& rO = o.rO; f3& rD = o.rD; f3& rW = o.rW; f3& tW = o.tW; f3& wl = o.wl;
+	float (&kd)[3] = o.kd; float (&ks)[3] = o.ks; float& shininess = o.shininess;
 	// what this ray adds to its pixel by itself: the background it ran into (q1.cpp:143-145 / objects.cpp:68-69,94-95) or the ambient
 	// term of its hit, and the background a reflected ray beyond the depth limit would have fetched; sent at the end of the kernel
-	f3 own = w * background, beyond = mk3(0, 0, 0);
-	bool hasOwn = live && !hit, hasBeyond = false;
+	own = w * background; beyond = mk3(0, 0, 0);
+	hasOwn = live && !hit; hasBeyond = false;
 	if (!MULTI && hasOwn) accumAdd(A, pixel, own);
 	if (PICK && live && !hit && path > 1u) pickEmit(pick, path, RT_PICK_MISS, 0, 0, mk3(0, 0, 0));
 
-	bool wantR = false, wantX = false, wantS = false;
-	bool wantTex = false;      // TEXFIX: a hit on a reflective textured triangle leaves a record (RtTexFix)
-	uint32_t texTri = 0;
-	float refraction = 0;
-	f3 p = mk3(0, 0, 0), N = mk3(0, 0, 0), V = mk3(0, 0, 0);
-	f3 rO = p, rD = p, rW = p, tW = p, wl = p;
-	float kd[3] = { 0, 0, 0 }, ks[3] = { 0, 0, 0 }, shininess = 0;
+	wantR = false; wantX = false; wantS = false;
+	wantTex = false;      // TEXFIX: a hit on a reflective textured triangle leaves a record (RtTexFix)
+	texTri = 0;
+	refraction = 0;
+	p = mk3(0, 0, 0); N = mk3(0, 0, 0); V = mk3(0, 0, 0);
+	rO = p; rD = p; rW = p; tW = p; wl = p;
+	kd[0] = kd[1] = kd[2] = 0; ks[0] = ks[1] = ks[2] = 0; shininess = 0;
 	if (hit) {
 		const uint32_t type = RT_PRIM_TYPE(prim), ix = RT_PRIM_INDEX(prim);
 		p = e + t * d;   // cachedHitpoint of the winner (every rayhit sets e + t*d)
@@ -1408,7 +1394,7 @@ __global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX || MULTI) ? 1 : 8) v
 				if (TEXFIX && !isZero3(m.reflective)) { wantTex = true; texTri = ix; }
 			}
 		} else if (type == RT_PRIM_BOX) boxNormal(S.boxes[ix].b, p, N);
-		else if (CSG) N = csgNormal(S, S.csgs[ix], e, d, qu(hq, HQ_TAG, i));
+		else if (CSG) N = csgNormal(S, S.csgs[ix], e, d, tagOf());
 
 		const bool transmissive = !isZero3(m.transmissive);
 		const f3 kt = ld3(m.transmissive);
@@ -1438,6 +1424,44 @@ __global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX || MULTI) ? 1 : 8) v
 		if (transmissive) { wantX = true; tW = w * kt; refraction = m.refraction; }
 		wantS = wantSurfaces != 0;
 	}
+
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// shade: everything Object::lightPoint does except the shadow rays
+// ---------------------------------------------------------------------------------------------------------
+// (the plain variant fits 64 VGPRs without spilling: 8 waves per SIMD, so that it shares a SIMD with whatever the other lanes run: +1 % on C2)
+// MULTI: several samples per pixel -- the accumulator atomics of neighbouring lanes are combined first (accumAddRows)
+template <bool CSG, bool PICK, bool TEXFIX, bool MULTI>
+__global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX || MULTI) ? 1 : 8) void k_shade(DevScene S, RtQueue rq, RtQueue hq, uint32_t nArg, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
+                                                  RtAccum A, uint32_t aaSq, int maxDepth, int wantSurfaces,
+                                                  uint8_t* outHit, int32_t* outId, float* outT, RtPick pick, RtTexFix tex) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t n = deviceCount(nArg, nDev);
+	if (blockIdx.x * kBlock >= n) return;   // (workgroup-uniform: a launch sized by a bound leaves its surplus workgroups at once)
+	// every record is read at once (index clamped, result masked): one memory round trip instead of two
+	const uint32_t ic = i < n ? i : 0u;
+	uint32_t pixKey = qu(rq, RQ_PIX, ic), path = qu(rq, RQ_PATH, ic), prim = qu(hq, HQ_PRIM, ic);
+	f3 e = mk3(qf(rq, RQ_OX, ic), qf(rq, RQ_OY, ic), qf(rq, RQ_OZ, ic));
+	f3 d = mk3(qf(rq, RQ_DX, ic), qf(rq, RQ_DY, ic), qf(rq, RQ_DZ, ic));
+	f3 w = mk3(qf(rq, RQ_WR, ic), qf(rq, RQ_WG, ic), qf(rq, RQ_WB, ic));
+	float t = qf(hq, HQ_T, ic);
+	const bool live = i < n && pixKey != kInactive;
+	if (!live) { pixKey = 0; path = 1; prim = RT_NO_HIT; e = mk3(0, 0, 0); d = mk3(0, 0, 1); w = mk3(0, 0, 0); t = 0; }
+	const uint32_t pixel = pixKey / aaSq;
+	const bool hit = live && prim != RT_NO_HIT;
+	const f3 background = ld3(S.background);
+	if (live && path == 1u && outHit) {   // first-level results for rt_trace_batch
+		outHit[pixKey] = hit;
+		if (outId) outId[pixKey] = hit ? primId(S, prim) : -1;
+		if (outT) outT[pixKey] = hit ? t : 0.0f;
+	}
+	ShadeOut o;
+	shadeRay<CSG, PICK, TEXFIX, MULTI>(S, live, hit, prim, t, e, d, w, pixel, path, background, A, maxDepth, wantSurfaces, pick, [&] { return qu(hq, HQ_TAG, i); }, o);
+	const bool wantR = o.wantR, wantX = o.wantX, wantS = o.wantS, wantTex = o.wantTex, hasOwn = o.hasOwn, hasBeyond = o.hasBeyond;
+	const uint32_t texTri = o.texTri; const float refraction = o.refraction, shininess = o.shininess;
+	const f3 own = o.own, beyond = o.beyond, p = o.p, N = o.N, V = o.V, rO = o.rO, rD = o.rD, rW = o.rW, tW = o.tW, wl = o.wl;
+	const float* kd = o.kd; const float* ks = o.ks;
 
 	// ---- convergent part: compacted appends, ONE atomic per counter per workgroup.  An append counter is a single
 	// address, and a single address takes ~90 atomics per microsecond on this GPU: with one atomic per wave (32 400 waves
@@ -1513,6 +1537,147 @@ __global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX || MULTI) ? 1 : 8) v
 		} else ctr->overflow = 1;
 	}
 	if (MULTI) accumAddRows(A, pixel, own, hasOwn, beyond, hasBeyond);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One kernel per DEEPER level (round 3).  Below level 0 a level of the bundled scenes is a few hundred thousand incoherent rays at
+// most, and walking, shading and lighting them in four launches (k_intersect, k_shade, k_publish, k_shadow_point) cost 50 us per
+// level of which most was launch-to-launch latency and the queues in between (hit records, 84 B surface records): scene a, seventeen
+// levels of mirrors, spent 0.8 of its 1.0 ms there.  Here one lane takes one ray through all of it: BVH::findNearest (the per-lane
+// walk), Object::lightPoint's own part (shadeRay), the shadow rays towards the point-type lights (per-lane any-hit walks, as in
+// k_shadow_point) -- hit and surface never leave the registers -- and the compacted appends of its children.  Exit searches of
+// transmitted rays stay in k_transmit (a few trapped rays would hold their waves), area lights in k_shadow_area (their samples fill
+// a wave per surface): for those the requests / surface records are written as k_shade writes them.  Same device functions, same
+// arithmetic, integer pixel sums: frames are bit-identical to the four-kernel form (Run::levels keeps that form for counting and
+// timing runs, and the tests compare the two).
+// `surfaces`: 0 = the scene has no lights that cast shadow rays, 1 = count the hits (rt_stats), 2 = also write their records.
+__device__ __forceinline__ void pointLightGeometry(const rt_light& L, f3 p, f3& Ld, f3& lightPos);
+//
+// SMALL: the scene's arrays that the walks and the shading read -- tree, leaf lists, primitives, planes, materials, lights, CSG programs:
+// RtSmallScene, one blob assembled at upload when they come to a few tens of KB, which holds for every scene the reference ships -- are
+// copied into the workgroup's LDS first and the DevScene the device functions see points there.  A ray of such a level is a chain of
+// some thirty dependent loads (node, leaf entry, primitive, ... for the nearest hit and again for every light) at 0.5 - 1 us each from
+// the caches: that chain, not arithmetic or bandwidth, was the length of the launch.  From LDS a link costs a tenth.  The per-lane
+// stack comes out of the same dynamic LDS, sized by the tree's depth.
+template <bool CSG, bool SMALL>
+__global__ __launch_bounds__(kBlock) void k_level(DevScene Sg, RtSmallScene small, RtQueue rq, uint32_t nArg, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
+                                                  RtAccum A, uint32_t aaSq, int maxDepth, int surfaces, const int32_t* lightList, uint32_t nLights) {
+	extern __shared__ uint4 levelLds[];
+	__shared__ int32_t stackStatic[SMALL ? 1 : kStack][kBlock];
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t n = deviceCount(nArg, nDev);
+	if (blockIdx.x * kBlock >= n) return;   // (workgroup-uniform: a launch sized by a bound leaves its surplus workgroups at once)
+	DevScene S = Sg;
+	int32_t (*stack)[kBlock] = stackStatic;
+	if (SMALL) {
+		stack = reinterpret_cast<int32_t (*)[kBlock]>(levelLds);
+		uint4* blob = levelLds + small.stackRows * (kBlock * 4u / 16u);
+		for (uint32_t k = threadIdx.x; k < small.bytes / 16u; k += kBlock) blob[k] = small.blob[k];
+		__syncthreads();
+		const char* base = reinterpret_cast<const char*>(blob);
+		S.treelets = reinterpret_cast<const float4*>(base + small.off[RT_SMALL_TREELETS]);
+		S.leaf_prims = reinterpret_cast<const uint32_t*>(base + small.off[RT_SMALL_LEAF_PRIMS]);
+		S.spheres = reinterpret_cast<const rt_sphere*>(base + small.off[RT_SMALL_SPHERES]);
+		S.boxes = reinterpret_cast<const rt_box*>(base + small.off[RT_SMALL_BOXES]);
+		S.planes = reinterpret_cast<const rt_plane*>(base + small.off[RT_SMALL_PLANES]);
+		S.materials = reinterpret_cast<const rt_material*>(base + small.off[RT_SMALL_MATERIALS]);
+		S.lights = reinterpret_cast<const rt_light*>(base + small.off[RT_SMALL_LIGHTS]);
+		S.csgs = reinterpret_cast<const rt_csg*>(base + small.off[RT_SMALL_CSGS]);
+		S.csg_nodes = reinterpret_cast<const rt_csg_node*>(base + small.off[RT_SMALL_CSG_NODES]);
+		if (small.off[RT_SMALL_TRIS] != 0xffffffffu) S.tris = reinterpret_cast<const rt_tri*>(base + small.off[RT_SMALL_TRIS]);
+		lightList = reinterpret_cast<const int32_t*>(base + small.off[RT_SMALL_LIGHT_LIST]);
+	}
+	const uint32_t ic = i < n ? i : 0u;
+	uint32_t pixKey = qu(rq, RQ_PIX, ic), path = qu(rq, RQ_PATH, ic);
+	f3 e = mk3(qf(rq, RQ_OX, ic), qf(rq, RQ_OY, ic), qf(rq, RQ_OZ, ic));
+	f3 d = mk3(qf(rq, RQ_DX, ic), qf(rq, RQ_DY, ic), qf(rq, RQ_DZ, ic));
+	f3 w = mk3(qf(rq, RQ_WR, ic), qf(rq, RQ_WG, ic), qf(rq, RQ_WB, ic));
+	const bool live = i < n && pixKey != kInactive;
+	if (!live) { pixKey = 0; path = 1; e = mk3(0, 0, 0); d = mk3(0, 0, 1); w = mk3(0, 0, 0); }
+	// BVH::findNearest, bvh.cpp:72-121
+	Trav T;
+	T.cur = kEmpty; T.sp = 0; T.best = RT_NO_HIT; T.tmin = 0; T.bestTag = 0; T.cntNodes = 0; T.cntPrims = 0; T.cntSteps = 0;
+	if (live) travInit<false>(S, T, e, d);
+	while (T.cur != kEmpty) travRound<false, CSG, false>(S, stack, T);
+	const uint32_t prim = live ? T.best : RT_NO_HIT;
+	const bool hit = prim != RT_NO_HIT;
+	const float t = hit ? T.tmin : 0.0f;
+	const uint32_t bestTag = T.bestTag;
+	const uint32_t pixel = pixKey / aaSq;
+	// Object::lightPoint, objects.cpp:54-105
+	ShadeOut o;
+	shadeRay<CSG, false, false, false>(S, live, hit, prim, t, e, d, w, pixel, path, ld3(S.background), A, maxDepth, surfaces, RtPick{ nullptr, nullptr, 0 }, [&] { return bestTag; }, o);
+	// compacted appends, one atomic per counter per workgroup (see k_shade)
+	uint32_t sr, st, ss;
+	{
+		__shared__ uint32_t waveCount[kBlock / 64][3];
+		__shared__ uint32_t blockBase[3];
+		const unsigned long long mR = __ballot(o.wantR), mT = __ballot(o.wantX), mS = __ballot(o.wantS);
+		const uint32_t lane = __lane_id(), wv = threadIdx.x >> 6;
+		if (lane == 0) { waveCount[wv][0] = (uint32_t)__popcll(mR); waveCount[wv][1] = (uint32_t)__popcll(mT); waveCount[wv][2] = (uint32_t)__popcll(mS); }
+		__syncthreads();
+		uint32_t beforeN = 0, beforeS = 0, totalN = 0, totalS = 0, beforeX = 0, totalX = 0;
+		for (uint32_t k = 0; k < kBlock / 64; k++) {
+			const uint32_t cn = waveCount[k][0], cx = waveCount[k][1], cs = waveCount[k][2];
+			if (k < wv) { beforeN += cn; beforeX += cx; beforeS += cs; }
+			totalN += cn; totalX += cx; totalS += cs;
+		}
+		if (threadIdx.x == 0 && totalN > 0) blockBase[0] = atomicAdd(&ctr->next_count, totalN);
+		if (threadIdx.x == 64 && totalS > 0) blockBase[1] = atomicAdd(&ctr->surf_count, totalS);
+		if (threadIdx.x == 128 && totalX > 0) blockBase[2] = atomicAdd(&ctr->trans_count, totalX);
+		__syncthreads();
+		const unsigned long long below = (1ull << lane) - 1ull;
+		sr = blockBase[0] + beforeN + (uint32_t)__popcll(mR & below);
+		st = blockBase[2] + beforeX + (uint32_t)__popcll(mT & below);
+		ss = blockBase[1] + beforeS + (uint32_t)__popcll(mS & below);
+	}
+	if (o.wantR) {
+		if (sr < nq.cap) {
+			qsf(nq, RQ_OX, sr, o.rO.x); qsf(nq, RQ_OY, sr, o.rO.y); qsf(nq, RQ_OZ, sr, o.rO.z);
+			qsf(nq, RQ_DX, sr, o.rD.x); qsf(nq, RQ_DY, sr, o.rD.y); qsf(nq, RQ_DZ, sr, o.rD.z);
+			qsf(nq, RQ_WR, sr, o.rW.x); qsf(nq, RQ_WG, sr, o.rW.y); qsf(nq, RQ_WB, sr, o.rW.z);
+			qsu(nq, RQ_PIX, sr, pixKey); qsu(nq, RQ_PATH, sr, path * 2u);
+		} else ctr->overflow = 1;
+	}
+	if (o.wantX) {
+		if (st < tq.cap) {
+			qsu(tq, TQ_PRIM, st, prim);
+			qsf(tq, TQ_PX, st, o.p.x); qsf(tq, TQ_PY, st, o.p.y); qsf(tq, TQ_PZ, st, o.p.z);
+			qsf(tq, TQ_DX, st, d.x); qsf(tq, TQ_DY, st, d.y); qsf(tq, TQ_DZ, st, d.z);
+			qsf(tq, TQ_NX, st, o.N.x); qsf(tq, TQ_NY, st, o.N.y); qsf(tq, TQ_NZ, st, o.N.z);
+			qsf(tq, TQ_REFR, st, o.refraction);
+			qsf(tq, TQ_WR, st, o.tW.x); qsf(tq, TQ_WG, st, o.tW.y); qsf(tq, TQ_WB, st, o.tW.z);
+			qsu(tq, TQ_PIX, st, pixKey); qsu(tq, TQ_PATH, st, path);
+		} else ctr->overflow = 1;
+	}
+	if (o.wantS && surfaces == 2) {   // area lights: k_shadow_area reads the surface from its record
+		if (ss < sq.cap) {
+			qsf(sq, SQ_PX, ss, o.p.x); qsf(sq, SQ_PY, ss, o.p.y); qsf(sq, SQ_PZ, ss, o.p.z);
+			qsf(sq, SQ_NX, ss, o.N.x); qsf(sq, SQ_NY, ss, o.N.y); qsf(sq, SQ_NZ, ss, o.N.z);
+			qsf(sq, SQ_VX, ss, o.V.x); qsf(sq, SQ_VY, ss, o.V.y); qsf(sq, SQ_VZ, ss, o.V.z);
+			qsf(sq, SQ_KDR, ss, o.kd[0]); qsf(sq, SQ_KDG, ss, o.kd[1]); qsf(sq, SQ_KDB, ss, o.kd[2]);
+			qsf(sq, SQ_KSR, ss, o.ks[0]); qsf(sq, SQ_KSG, ss, o.ks[1]); qsf(sq, SQ_KSB, ss, o.ks[2]);
+			qsf(sq, SQ_SHIN, ss, o.shininess);
+			qsf(sq, SQ_WR, ss, o.wl.x); qsf(sq, SQ_WG, ss, o.wl.y); qsf(sq, SQ_WB, ss, o.wl.z);
+			qsu(sq, SQ_PIX, ss, pixKey); qsu(sq, SQ_PATH, ss, path);
+		} else ctr->overflow = 1;
+	}
+	// Directional / Point / Spot::lightPoint, objects.cpp:399-458 -> BVH::calcShadow, bvh.cpp:123-160: as k_shadow_point, on the surface in registers
+	if (hit) {
+		for (uint32_t l = 0; l < nLights; l++) {
+			const rt_light L = S.lights[lightList[l]];
+			f3 Ld, lightPos;
+			pointLightGeometry(L, o.p, Ld, lightPos);
+			Trav Ts;
+			Ts.cur = kEmpty; Ts.sp = 0;
+			travInit<true>(S, Ts, o.p, lightPos - o.p);   // bvh.cpp:124
+			while (Ts.cur != kEmpty) travRound<true, CSG, false>(S, stack, Ts);
+			if (Ts.lit && !(L.type == RT_LIGHT_SPOT && !((double)dot(Ld, -ld3(L.direction)) > L.cos_cutoff))) {   // objects.cpp:451
+				const f3 c = phong(ld3(L.colour) * Ts.shadow, o.kd, o.ks, o.shininess, o.N, Ld, o.V);
+				accumAdd(A, pixel, o.wl * c);
+			}
+		}
+	}
 }
 
 // Transmitted rays (objects.cpp:81-104): one request per lane.  The launch covers the most requests the level could have
@@ -2194,6 +2359,17 @@ void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue 
 	if (csg) { if (multi) RT_SHADE(true, false, false, true); else RT_SHADE(true, false, false, false); }
 	else { if (multi) RT_SHADE(false, false, false, true); else RT_SHADE(false, false, false, false); }
 #undef RT_SHADE
+}
+void rtk_level(hipStream_t st, const DevScene& S, const RtSmallScene& small, bool csg, RtQueue rq, uint32_t n, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
+               uint32_t aaSq, int maxDepth, int surfaces, const int32_t* lightList, uint32_t nLights) {
+	if (small.blob && getenv("RT_NO_SMALL_SCENE") == nullptr) {   // (the switch: read per call, for the tests)
+		const size_t lds = (size_t)small.stackRows * kBlock * 4u + small.bytes;
+		if (csg) RT_LAUNCH_S((k_level<true, true>), n, lds, st, S, small, rq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, surfaces, lightList, nLights);
+		else RT_LAUNCH_S((k_level<false, true>), n, lds, st, S, small, rq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, surfaces, lightList, nLights);
+		return;
+	}
+	if (csg) RT_LAUNCH((k_level<true, false>), n, st, S, small, rq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, surfaces, lightList, nLights);
+	else RT_LAUNCH((k_level<false, false>), n, st, S, small, rq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, surfaces, lightList, nLights);
 }
 void rtk_texel_fix(hipStream_t st, const DevScene& S, bool csg, RtTexFix tex, uint32_t count, RtCounters* ctr, RtAccum A, uint32_t aaSq, uint32_t seed, bool apply) {
 	if (!tex.rec || count == 0) return;

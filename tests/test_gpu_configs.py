@@ -4,6 +4,8 @@ reference at 256x144 (tests/golden/ref_c2_224.npz); whole 1080p frames are beyon
   * size-independent properties: the frame is bit-identical run to run, any tile sharding composes to the same frame, and
     the two traversal forms (packets for camera rays, per-lane walks for caller-supplied rays) give bit-identical images,
   * ray counts equal to the oracle's BVH::findNearest / BVH::calcShadow counts on a reduced frame."""
+import json
+
 import numpy as np
 import pytest
 
@@ -520,6 +522,62 @@ def test_row_sums_of_multi_sample_frames_are_exact(tmp_path, monkeypatch, gpu_sc
         assert rays == (scene.last_stats["rays_nearest"], scene.last_stats["rays_shadow"])
         assert np.array_equal(bits(a), bits(b))
     sc.close()
+
+
+@pytest.mark.parametrize("name", ["a", "b", "e", "g", "h", "i", "l", "c3", "c4mirror", "c2mirror"])
+def test_one_launch_per_deeper_level_equals_the_four_kernel_form(tmp_path, monkeypatch, gpu_scenes, name):
+    """Below level 0 one launch walks, shades and lights a ray (k_level), and for small scenes -- all the reference ships -- with the scene's
+    arrays copied into LDS first.  Same device functions and integer pixel sums, so the frame must equal, bit for bit and in both ray
+    counts, the one the queues and the four kernels give (RT_NO_FUSED_LEVELS) and the one walked in memory (RT_NO_SMALL_SCENE): mirrors
+    (a), refraction (b, g: a refractive mesh, h: both at every hit), the 242-triangle meshes whose tree nearly fills the LDS budget (i),
+    CSG (l, C3's 64 objects at depth 5), area lights, whose surface records k_level still writes (the C4 room with a mirror floor), and a
+    scene too large for the LDS copy (a reflective 4 608-triangle height field)."""
+    kw = {}
+    if name == "c3":
+        flat = rt.FlatScene.from_json(scenes.c3_scene(str(tmp_path)))
+        sc, W, H = rt.Scene(flat, 0), 240, 135
+        kw = dict(camera=rt.Camera(flat.fov, W, H, eye=(0, 1.0, 2.0), rot_x=-0.25), max_depth=5)
+    elif name == "c4mirror":
+        doc = json.load(open(scenes.c4_scene(str(tmp_path), 8)))
+        plane = next(o for o in doc["objects"] if o["type"] == "plane")
+        plane.setdefault("material", {})["reflective"] = [0.5, 0.5, 0.5]
+        path = str(tmp_path / "c4mirror.json")
+        json.dump(doc, open(path, "w"))
+        flat = rt.FlatScene.from_json(path)
+        sc, W, H = rt.Scene(flat, 0), 160, 90
+        kw = dict(max_depth=4)
+    elif name == "c2mirror":
+        doc = json.load(open(scenes.c2_scene(str(tmp_path), grid=48)))
+        mesh, s1, s2 = doc["objects"][:3]
+        mesh["type"] = "mesh"
+        mesh.pop("texture"); mesh.pop("uvCoords")
+        mesh["material"]["diffuse"] = [0.5, 0.6, 0.4]
+        mesh["material"]["reflective"] = [0.4, 0.4, 0.4]
+        for sph in (s1, s2):
+            sph["type"] = "sphere"
+            sph.pop("bumpmap"); sph.pop("bumpdepth")
+        s2["material"]["transmissive"] = [0.6, 0.6, 0.6]
+        s2["material"]["refraction"] = 1.3
+        path = str(tmp_path / "mirror.json")
+        json.dump(doc, open(path, "w"))
+        flat = rt.FlatScene.from_json(path)
+        sc, W, H = rt.Scene(flat, 0), 200, 120
+        kw = dict(camera=rt.Camera(flat.fov, W, H, eye=(0, 1.5, 1.0), rot_x=-0.3), max_depth=6)
+    else:
+        sc, W, H = gpu_scenes(name), 160, 120
+    for var in ("RT_NO_FUSED_LEVELS", "RT_NO_SMALL_SCENE"):
+        monkeypatch.delenv(var, raising=False)
+    a = sc.render(W, H, seed=5, **kw)
+    st = dict(sc.last_stats)
+    assert st["levels"] > 1
+    for var in ("RT_NO_SMALL_SCENE", "RT_NO_FUSED_LEVELS"):
+        monkeypatch.setenv(var, "1")
+        b = sc.render(W, H, seed=5, **kw)
+        assert (st["rays_nearest"], st["rays_shadow"], st["levels"]) == (sc.last_stats["rays_nearest"], sc.last_stats["rays_shadow"], sc.last_stats["levels"]), var
+        assert np.array_equal(bits(a), bits(b)), var
+        monkeypatch.delenv(var)
+    if name in ("c3", "c2mirror", "c4mirror"):
+        sc.close()
 
 
 @pytest.mark.parametrize("samples", [64, 24])

@@ -119,6 +119,7 @@ struct rt_scene {
 	RtTexFix texFix(const Lane& ln) const { return RtTexFix{ texelFix ? ln.texRec : nullptr, texHeads, texCap, &ln.ctr->texrec_count }; }
 	uint32_t qcap = 0;
 	int maxBlocks = 2048;            // grid cap of the persistent kernels
+	bool transmitAnalytic = false;   // no CSG object and no triangle of the scene transmits: exit searches are one analytic test per internal reflection (k_level does them inline)
 	RtSmallScene small;              // the scene's walk / shading arrays as one blob for k_level's LDS copy (small scenes only)
 	int maxBlocksPacketNear = 2048;  // ... of the nearest-hit packet kernel (see rt_scene_upload)
 	int maxBlocksPacketShadow = 2048;   // ... and of the shadow packet kernels (one light per packet / two)
@@ -856,17 +857,26 @@ struct Run {
 				const bool packets = coherent(lv);
 				// deeper levels (incoherent rays): one launch walks, shades and lights a ray (k_level); level 0 and scenes that keep texel records
 				// go through the queues (RT_NO_FUSED_LEVELS: everything does -- read per call, the tests compare the two forms)
-				const bool fused = !packets && lv > 0 && !sc->texelFix && getenv("RT_NO_FUSED_LEVELS") == nullptr;
-				if (fused) rtk_level(st, sc->dev, sc->small, sc->hasCsg, ln->ray[cur], nb, nDev, ln->ray[cur ^ 1], ln->surfq, ln->transq, &L[lv], sc->accum, aaSq, maxDepth,
-				                     !shadows ? 0 : sc->areaLights.empty() ? 1 : 2, sc->pointLights, (uint32_t)sc->nPointLights);
+				// Level 0 of a SMALL scene's frame goes the same way (RT_NO_SMALL_LEVEL0: through the packet kernels): with the scene in LDS a
+				// camera ray's walk is a few hundred instructions, while the persistent packet kernels, built for trees of 10^5 triangles, take
+				// 60 us a launch whatever the scene (their launch tails; measured on the bundled scenes).
+				const bool smallLevel0 = lv == 0 && src.camera && !src.outHit && sc->small.blob && aaSq <= 2 && getenv("RT_NO_SMALL_LEVEL0") == nullptr && getenv("RT_NO_SMALL_SCENE") == nullptr;
+				const bool fused = ((!packets && lv > 0) || smallLevel0) && !sc->texelFix && getenv("RT_NO_FUSED_LEVELS") == nullptr;
+				// ... and the exit searches of transmitted rays as well where they are analytic (no CSG object, no triangle transmits): such a
+				// level, like one of a scene without transmission, is a single launch that also reports its counts
+				const bool inlineX = fused && sc->hasTransmissive && sc->transmitAnalytic && getenv("RT_NO_INLINE_TRANSMIT") == nullptr;
+				const bool selfReport = fused && (!sc->hasTransmissive || inlineX) && getenv("RT_NO_SELF_REPORT") == nullptr;
+				seqOf[lv] = ++ln->reportSeq ? ln->reportSeq : ++ln->reportSeq;   // (never 0)
+				if (fused) rtk_level(st, sc->dev, sc->small, sc->hasCsg, inlineX, ln->ray[cur], nb, nDev, ln->ray[cur ^ 1], ln->surfq, ln->transq, &L[lv], sc->accum, aaSq, maxDepth,
+				                     !shadows ? 0 : sc->areaLights.empty() ? 1 : 2, sc->pointLights, (uint32_t)sc->nPointLights,
+				                     sc->hasTransmissive ? &ln->ctr->state_cases : nullptr, selfReport ? ln->reportDev + lv : nullptr, seqOf[lv]);
 				else {
 				rtk_intersect(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketNear : sc->maxBlocks, ln->ray[cur], nb, ln->hitq, &L[lv], nDev);
 				rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, nb, ln->ray[cur ^ 1], ln->surfq, ln->transq, &L[lv], sc->accum, aaSq, maxDepth,
 				          shadows, lv == 0 ? src.outHit : nullptr, src.outId, src.outT, pick, sc->texFix(*ln), nDev);
 				}
-				if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, nb, ln->ray[cur ^ 1], &L[lv], &ln->ctr->state_cases, sc->accum, aaSq, maxDepth, pick);
-				seqOf[lv] = ++ln->reportSeq ? ln->reportSeq : ++ln->reportSeq;   // (never 0)
-				rtk_publish(st, &L[lv], sc->texelFix ? &ln->ctr->texrec_count : nullptr, sc->hasTransmissive ? &ln->ctr->state_cases : nullptr, ln->reportDev + lv, seqOf[lv]);
+				if (sc->hasTransmissive && !inlineX) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, nb, ln->ray[cur ^ 1], &L[lv], &ln->ctr->state_cases, sc->accum, aaSq, maxDepth, pick);
+				if (!selfReport) rtk_publish(st, &L[lv], sc->texelFix ? &ln->ctr->texrec_count : nullptr, sc->hasTransmissive ? &ln->ctr->state_cases : nullptr, ln->reportDev + lv, seqOf[lv]);
 				if (shadows) {
 					if (sc->nPointLights && !fused) rtk_shadow_point(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nb, sc->pointLights, sc->nPointLights, sc->accum, aaSq, &L[lv], true, sc->maxBlocksPacketShadow2);
 					for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, sc->nCsg, false, ln->surfq, nb, al.first, al.second, seed, sc->accum, aaSq, &L[lv], true);
@@ -1191,6 +1201,9 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 		if (kr[0] != 0 || kr[1] != 0 || kr[2] != 0) sc->hasReflective = true;
 	}
 
+	sc->transmitAnalytic = sc->hasTransmissive;
+	for (int32_t i = 0; i < s->n_csgs && sc->transmitAnalytic; i++) { const float* kt = s->materials[s->csgs[i].mat].transmissive; if (kt[0] != 0 || kt[1] != 0 || kt[2] != 0) sc->transmitAnalytic = false; }
+	for (int64_t i = 0; i < s->n_tris && sc->transmitAnalytic; i++) { const float* kt = s->materials[s->tris[i].mat].transmissive; if (kt[0] != 0 || kt[1] != 0 || kt[2] != 0) sc->transmitAnalytic = false; }
 	for (int64_t i = 0; i < s->n_tris && !sc->texelFix; i++) {
 		const float* kr = s->materials[s->tris[i].mat].reflective;
 		if (s->tris[i].uv >= 0 && (kr[0] != 0 || kr[1] != 0 || kr[2] != 0) && getenv("RT_NO_TEXEL_FIX") == nullptr) sc->texelFix = true;

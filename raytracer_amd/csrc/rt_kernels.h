@@ -163,9 +163,11 @@ struct RtSmallScene {
 	uint32_t off[RT_SMALL_SECTIONS] = {};   // byte offsets of the sections; RT_SMALL_TRIS: 0xffffffff when the triangles did not fit (they stay in memory)
 };
 // a deeper level in one launch: nearest hits, shading, shadow rays towards the `nLights` point-type lights of lightList, appends (k_level);
-// surfaces: 0 no shadow-casting lights, 1 count the hits, 2 also write their surface records (area lights: k_shadow_area follows)
-void rtk_level(hipStream_t st, const DevScene& S, const RtSmallScene& small, bool csg, RtQueue rq, uint32_t n, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
-               uint32_t aaSq, int maxDepth, int surfaces, const int32_t* lightList, uint32_t nLights);
+// surfaces: 0 no shadow-casting lights, 1 count the hits, 2 also write their surface records (area lights: k_shadow_area follows).
+// inlineTransmit: exit searches of transmitted rays too (no CSG object and no triangle of the scene may transmit); otherwise requests
+// for k_transmit are written.  report (may be null): the level's counts go to the host from this launch (no k_publish behind it).
+void rtk_level(hipStream_t st, const DevScene& S, const RtSmallScene& small, bool csg, bool inlineTransmit, RtQueue rq, uint32_t n, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq,
+               RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth, int surfaces, const int32_t* lightList, uint32_t nLights, uint32_t* stateCases, RtLevelReport* report, uint32_t seq);
 // after the last level of a batch: the corrections for `count` records, then the lists and the record counter are emptied again
 void rtk_texel_fix(hipStream_t st, const DevScene& S, bool csg, RtTexFix tex, uint32_t count, RtCounters* ctr, RtAccum A, uint32_t aaSq, uint32_t seed, bool apply);
 void rtk_shadow_point(hipStream_t st, const DevScene& S, bool csg, bool count, bool coherent, int maxBlocks, RtQueue sq, uint32_t nsurf, const int32_t* lightList, uint32_t nLights,

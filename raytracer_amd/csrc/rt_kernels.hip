@@ -1269,7 +1269,7 @@ __device__ __forceinline__ void pickEmit(const RtPick& P, uint32_t path, int kin
 // Where the exit search on the ray's own object fails, the reference continues from whatever an earlier ray left in
 // the object's hit cache; like the oracle restatement this uses the current point / previous normal instead.
 // ---------------------------------------------------------------------------------------------------------
-template <bool CSG, bool PICK, class Store>
+template <bool CSG, bool PICK, class Store, bool TRIS = true>
 __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refraction, f3 inPoint, f3 inVector, f3 inNormal, f3& outPoint, f3& outVector, Store& csgStore,
                                    const RtPick& pick, uint32_t path, uint32_t& failedSearches) {
 	const uint32_t type = RT_PRIM_TYPE(ref), ix = RT_PRIM_INDEX(ref);
@@ -1300,7 +1300,7 @@ __device__ inline bool transmitRay(const DevScene& S, uint32_t ref, float refrac
 			// "missed" (no write) or "exactly at the origin" (write of e + 0*d = e): both leave hp == currentPoint.
 			if (t > 0.0f) hp = currentPoint + t * innerVector;
 			outNormal = sphereNormal(S, s, hp);
-		} else if (type == RT_PRIM_TRI) {
+		} else if (TRIS && type == RT_PRIM_TRI) {   // (TRIS false: the caller knows that no triangle of the scene transmits)
 			f3 nrm = outNormal;
 			const float t = meshHit(S, S.tris[ix].mesh, currentPoint, innerVector, true, nrm);
 			if (t > 0.0f) hp = currentPoint + t * innerVector;
@@ -1539,6 +1539,10 @@ __global__ __launch_bounds__(kBlock, (CSG || PICK || TEXFIX || MULTI) ? 1 : 8) v
 	if (MULTI) accumAddRows(A, pixel, own, hasOwn, beyond, hasBeyond);
 }
 
+// k_level: an append that found its queue full.  A returning atomic whose result is waited for, so that the flag is set at the memory
+// side before the lane goes on (the level's report, written from the same launch, must not miss it).
+__device__ __forceinline__ void levelOverflow(RtCounters* ctr) { const uint32_t was = atomicExch(&ctr->overflow, 1u); asm volatile("" :: "v"(was)); }
+
 // ---------------------------------------------------------------------------------------------------------
 // One kernel per DEEPER level (round 3).  Below level 0 a level of the bundled scenes is a few hundred thousand incoherent rays at
 // most, and walking, shading and lighting them in four launches (k_intersect, k_shade, k_publish, k_shadow_point) cost 50 us per
@@ -1559,9 +1563,18 @@ __device__ __forceinline__ void pointLightGeometry(const rt_light& L, f3 p, f3& 
 // some thirty dependent loads (node, leaf entry, primitive, ... for the nearest hit and again for every light) at 0.5 - 1 us each from
 // the caches: that chain, not arithmetic or bandwidth, was the length of the launch.  From LDS a link costs a tenth.  The per-lane
 // stack comes out of the same dynamic LDS, sized by the tree's depth.
-template <bool CSG, bool SMALL>
+//
+// XINLINE: the exit search of a transmitted ray (Object::transmitRay) happens here as well, right after the shading, instead of in a
+// k_transmit launch behind this one.  Only for scenes whose transmitting objects are spheres, boxes and planes -- one analytic exit
+// test per internal reflection; a CSG object or a mesh would hold the wave for a walk or an evaluation per reflection (rt_scene_upload
+// decides).  `report` (may be null): the level's counts for the host loop, written by the LAST workgroup to finish its appends (a
+// ticket per workgroup with work: a few hundred at most at these sizes) -- with that a deeper level is ONE launch instead of the
+// k_level / k_transmit / k_publish chain; a level with a k_transmit behind it leaves the report to k_publish.
+template <bool CSG, bool SMALL, bool XINLINE>
 __global__ __launch_bounds__(kBlock) void k_level(DevScene Sg, RtSmallScene small, RtQueue rq, uint32_t nArg, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
-                                                  RtAccum A, uint32_t aaSq, int maxDepth, int surfaces, const int32_t* lightList, uint32_t nLights) {
+                                                  RtAccum A, uint32_t aaSq, int maxDepth, int surfaces, const int32_t* lightList, uint32_t nLights,
+                                                  uint32_t* stateCases, RtLevelReport* report, uint32_t seq) {
+	static_assert(!(CSG && XINLINE), "exit searches on CSG objects stay in k_transmit");
 	extern __shared__ uint4 levelLds[];
 	__shared__ int32_t stackStatic[SMALL ? 1 : kStack][kBlock];
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -1607,12 +1620,30 @@ __global__ __launch_bounds__(kBlock) void k_level(DevScene Sg, RtSmallScene smal
 	// Object::lightPoint, objects.cpp:54-105
 	ShadeOut o;
 	shadeRay<CSG, false, false, false>(S, live, hit, prim, t, e, d, w, pixel, path, ld3(S.background), A, maxDepth, surfaces, RtPick{ nullptr, nullptr, 0 }, [&] { return bestTag; }, o);
+	// Object::transmitRay, objects.cpp:81-104 (k_transmit's body)
+	bool wantT = o.wantX;   // without XINLINE: a request for k_transmit; with it: a transmitted child for the next level
+	f3 tO = mk3(0, 0, 0), tD = tO;
+	if (XINLINE && o.wantX) {
+		f3 outPoint, outVector;
+		uint32_t failedSearches = 0;
+		CsgScratch store;
+		const bool ok = transmitRay<false, false, CsgScratch, false>(S, prim, o.refraction, o.p, d, o.N, outPoint, outVector, store, RtPick{ nullptr, nullptr, 0 }, path, failedSearches);
+		if (failedSearches != 0u) { const uint32_t was = atomicAdd(stateCases, failedSearches); asm volatile("" :: "v"(was)); }   // (returned: complete before the workgroup's ticket)
+		wantT = false;
+		if (ok) {
+			tO = outPoint;
+			tD = (outPoint + outVector) - outPoint;
+			const int depth = 31 - __clz((int)path);
+			if (depth + 1 > maxDepth) accumAdd(A, pixel, o.tW * ld3(S.background));   // raytracer.cpp:308-313 -> objects.cpp:94-95
+			else wantT = true;
+		}
+	}
 	// compacted appends, one atomic per counter per workgroup (see k_shade)
 	uint32_t sr, st, ss;
 	{
 		__shared__ uint32_t waveCount[kBlock / 64][3];
 		__shared__ uint32_t blockBase[3];
-		const unsigned long long mR = __ballot(o.wantR), mT = __ballot(o.wantX), mS = __ballot(o.wantS);
+		const unsigned long long mR = __ballot(o.wantR), mT = __ballot(wantT), mS = __ballot(o.wantS);
 		const uint32_t lane = __lane_id(), wv = threadIdx.x >> 6;
 		if (lane == 0) { waveCount[wv][0] = (uint32_t)__popcll(mR); waveCount[wv][1] = (uint32_t)__popcll(mT); waveCount[wv][2] = (uint32_t)__popcll(mS); }
 		__syncthreads();
@@ -1622,14 +1653,23 @@ __global__ __launch_bounds__(kBlock) void k_level(DevScene Sg, RtSmallScene smal
 			if (k < wv) { beforeN += cn; beforeX += cx; beforeS += cs; }
 			totalN += cn; totalX += cx; totalS += cs;
 		}
-		if (threadIdx.x == 0 && totalN > 0) blockBase[0] = atomicAdd(&ctr->next_count, totalN);
+		// (XINLINE: the transmitted children go into the next level's queue behind the workgroup's reflected ones)
+		if (threadIdx.x == 0 && totalN + (XINLINE ? totalX : 0u) > 0) blockBase[0] = atomicAdd(&ctr->next_count, totalN + (XINLINE ? totalX : 0u));
 		if (threadIdx.x == 64 && totalS > 0) blockBase[1] = atomicAdd(&ctr->surf_count, totalS);
-		if (threadIdx.x == 128 && totalX > 0) blockBase[2] = atomicAdd(&ctr->trans_count, totalX);
+		if (!XINLINE && threadIdx.x == 128 && totalX > 0) blockBase[2] = atomicAdd(&ctr->trans_count, totalX);
 		__syncthreads();
 		const unsigned long long below = (1ull << lane) - 1ull;
 		sr = blockBase[0] + beforeN + (uint32_t)__popcll(mR & below);
-		st = blockBase[2] + beforeX + (uint32_t)__popcll(mT & below);
+		st = (XINLINE ? blockBase[0] + totalN : blockBase[2]) + beforeX + (uint32_t)__popcll(mT & below);
 		ss = blockBase[1] + beforeS + (uint32_t)__popcll(mS & below);
+	}
+	if (XINLINE && wantT) {
+		if (st < nq.cap) {
+			qsf(nq, RQ_OX, st, tO.x); qsf(nq, RQ_OY, st, tO.y); qsf(nq, RQ_OZ, st, tO.z);
+			qsf(nq, RQ_DX, st, tD.x); qsf(nq, RQ_DY, st, tD.y); qsf(nq, RQ_DZ, st, tD.z);
+			qsf(nq, RQ_WR, st, o.tW.x); qsf(nq, RQ_WG, st, o.tW.y); qsf(nq, RQ_WB, st, o.tW.z);
+			qsu(nq, RQ_PIX, st, pixKey); qsu(nq, RQ_PATH, st, path * 2u + 1u);
+		} else levelOverflow(ctr);
 	}
 	if (o.wantR) {
 		if (sr < nq.cap) {
@@ -1637,9 +1677,9 @@ __global__ __launch_bounds__(kBlock) void k_level(DevScene Sg, RtSmallScene smal
 			qsf(nq, RQ_DX, sr, o.rD.x); qsf(nq, RQ_DY, sr, o.rD.y); qsf(nq, RQ_DZ, sr, o.rD.z);
 			qsf(nq, RQ_WR, sr, o.rW.x); qsf(nq, RQ_WG, sr, o.rW.y); qsf(nq, RQ_WB, sr, o.rW.z);
 			qsu(nq, RQ_PIX, sr, pixKey); qsu(nq, RQ_PATH, sr, path * 2u);
-		} else ctr->overflow = 1;
+		} else levelOverflow(ctr);
 	}
-	if (o.wantX) {
+	if (!XINLINE && wantT) {
 		if (st < tq.cap) {
 			qsu(tq, TQ_PRIM, st, prim);
 			qsf(tq, TQ_PX, st, o.p.x); qsf(tq, TQ_PY, st, o.p.y); qsf(tq, TQ_PZ, st, o.p.z);
@@ -1648,7 +1688,7 @@ __global__ __launch_bounds__(kBlock) void k_level(DevScene Sg, RtSmallScene smal
 			qsf(tq, TQ_REFR, st, o.refraction);
 			qsf(tq, TQ_WR, st, o.tW.x); qsf(tq, TQ_WG, st, o.tW.y); qsf(tq, TQ_WB, st, o.tW.z);
 			qsu(tq, TQ_PIX, st, pixKey); qsu(tq, TQ_PATH, st, path);
-		} else ctr->overflow = 1;
+		} else levelOverflow(ctr);
 	}
 	if (o.wantS && surfaces == 2) {   // area lights: k_shadow_area reads the surface from its record
 		if (ss < sq.cap) {
@@ -1660,7 +1700,30 @@ __global__ __launch_bounds__(kBlock) void k_level(DevScene Sg, RtSmallScene smal
 			qsf(sq, SQ_SHIN, ss, o.shininess);
 			qsf(sq, SQ_WR, ss, o.wl.x); qsf(sq, SQ_WG, ss, o.wl.y); qsf(sq, SQ_WB, ss, o.wl.z);
 			qsu(sq, SQ_PIX, ss, pixKey); qsu(sq, SQ_PATH, ss, path);
-		} else ctr->overflow = 1;
+		} else levelOverflow(ctr);
+	}
+	// The level's counts for the host (k_publish's job): every workgroup with work takes a ticket once its appends -- counters and a
+	// possible overflow flag -- are done, the last one reads the totals and writes the report.  Before the shadow rays: the host, which
+	// queues the next levels from these counts, hears of them that much earlier.
+	if (report) {
+		// No fences: an agent-scope release would write this XCD's L2 back (the eight L2s are not coherent with each other) once per
+		// workgroup.  Everything the report reads is the target of device-scope atomics, which execute at the memory side, and every one
+		// of them has RETURNED to its lane -- the three append counters before the barrier above, the overflow flag and the failed-search
+		// count where they are set -- before the barrier below, hence before this workgroup's ticket; the last ticket reads them back
+		// with atomics as well.  (The queues' contents need no such care: the next level is another launch.)
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const uint32_t expected = (n + kBlock - 1u) / kBlock;
+			if (atomicAdd(&ctr->reserved[0], 1u) == expected - 1u) {
+				report->texrec_count = 0u;   // (scenes that keep texel records do not come here)
+				report->state_cases = stateCases ? atomicAdd(stateCases, 0u) : 0u;
+				report->next_count = atomicAdd(&ctr->next_count, 0u);
+				report->surf_count = atomicAdd(&ctr->surf_count, 0u);
+				report->overflow = atomicAdd(&ctr->overflow, 0u);
+				__threadfence_system();
+				__hip_atomic_store(&report->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+		}
 	}
 	// Directional / Point / Spot::lightPoint, objects.cpp:399-458 -> BVH::calcShadow, bvh.cpp:123-160: as k_shadow_point, on the surface in registers
 	if (hit) {
@@ -2360,16 +2423,20 @@ void rtk_shade(hipStream_t st, const DevScene& S, bool csg, RtQueue rq, RtQueue 
 	else { if (multi) RT_SHADE(false, false, false, true); else RT_SHADE(false, false, false, false); }
 #undef RT_SHADE
 }
-void rtk_level(hipStream_t st, const DevScene& S, const RtSmallScene& small, bool csg, RtQueue rq, uint32_t n, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr, RtAccum A,
-               uint32_t aaSq, int maxDepth, int surfaces, const int32_t* lightList, uint32_t nLights) {
+void rtk_level(hipStream_t st, const DevScene& S, const RtSmallScene& small, bool csg, bool inlineTransmit, RtQueue rq, uint32_t n, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq,
+               RtCounters* ctr, RtAccum A, uint32_t aaSq, int maxDepth, int surfaces, const int32_t* lightList, uint32_t nLights, uint32_t* stateCases, RtLevelReport* report, uint32_t seq) {
+#define RT_LEVEL_ARGS S, small, rq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, surfaces, lightList, nLights, stateCases, report, seq
 	if (small.blob && getenv("RT_NO_SMALL_SCENE") == nullptr) {   // (the switch: read per call, for the tests)
 		const size_t lds = (size_t)small.stackRows * kBlock * 4u + small.bytes;
-		if (csg) RT_LAUNCH_S((k_level<true, true>), n, lds, st, S, small, rq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, surfaces, lightList, nLights);
-		else RT_LAUNCH_S((k_level<false, true>), n, lds, st, S, small, rq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, surfaces, lightList, nLights);
+		if (csg) RT_LAUNCH_S((k_level<true, true, false>), n, lds, st, RT_LEVEL_ARGS);
+		else if (inlineTransmit) RT_LAUNCH_S((k_level<false, true, true>), n, lds, st, RT_LEVEL_ARGS);
+		else RT_LAUNCH_S((k_level<false, true, false>), n, lds, st, RT_LEVEL_ARGS);
 		return;
 	}
-	if (csg) RT_LAUNCH((k_level<true, false>), n, st, S, small, rq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, surfaces, lightList, nLights);
-	else RT_LAUNCH((k_level<false, false>), n, st, S, small, rq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, surfaces, lightList, nLights);
+	if (csg) RT_LAUNCH((k_level<true, false, false>), n, st, RT_LEVEL_ARGS);
+	else if (inlineTransmit) RT_LAUNCH((k_level<false, false, true>), n, st, RT_LEVEL_ARGS);
+	else RT_LAUNCH((k_level<false, false, false>), n, st, RT_LEVEL_ARGS);
+#undef RT_LEVEL_ARGS
 }
 void rtk_texel_fix(hipStream_t st, const DevScene& S, bool csg, RtTexFix tex, uint32_t count, RtCounters* ctr, RtAccum A, uint32_t aaSq, uint32_t seed, bool apply) {
 	if (!tex.rec || count == 0) return;

@@ -524,11 +524,13 @@ def test_row_sums_of_multi_sample_frames_are_exact(tmp_path, monkeypatch, gpu_sc
     sc.close()
 
 
-@pytest.mark.parametrize("name", ["a", "b", "e", "g", "h", "i", "l", "c3", "c4mirror", "c2mirror"])
+@pytest.mark.parametrize("name", ["a", "b", "c", "e", "g", "h", "i", "j", "k", "l", "m", "c3", "c4mirror", "c2mirror"])
 def test_one_launch_per_deeper_level_equals_the_four_kernel_form(tmp_path, monkeypatch, gpu_scenes, name):
     """Below level 0 one launch walks, shades and lights a ray (k_level), and for small scenes -- all the reference ships -- with the scene's
-    arrays copied into LDS first.  Same device functions and integer pixel sums, so the frame must equal, bit for bit and in both ray
-    counts, the one the queues and the four kernels give (RT_NO_FUSED_LEVELS) and the one walked in memory (RT_NO_SMALL_SCENE): mirrors
+    arrays copied into LDS first, and then level 0 goes the same way instead of through the packet kernels (RT_NO_SMALL_LEVEL0; c, j: bump
+    maps and textures, k, m: one level only).  Same device functions and integer pixel sums, so the frame must equal, bit for bit and in both ray
+    counts, the one the queues and the four kernels give (RT_NO_FUSED_LEVELS), the one walked in memory (RT_NO_SMALL_SCENE), the one with the
+    exit searches of transmitted rays in k_transmit (RT_NO_INLINE_TRANSMIT) and the one whose counts k_publish reports (RT_NO_SELF_REPORT): mirrors
     (a), refraction (b, g: a refractive mesh, h: both at every hit), the 242-triangle meshes whose tree nearly fills the LDS budget (i),
     CSG (l, C3's 64 objects at depth 5), area lights, whose surface records k_level still writes (the C4 room with a mirror floor), and a
     scene too large for the LDS copy (a reflective 4 608-triangle height field)."""
@@ -565,12 +567,13 @@ def test_one_launch_per_deeper_level_equals_the_four_kernel_form(tmp_path, monke
         kw = dict(camera=rt.Camera(flat.fov, W, H, eye=(0, 1.5, 1.0), rot_x=-0.3), max_depth=6)
     else:
         sc, W, H = gpu_scenes(name), 160, 120
-    for var in ("RT_NO_FUSED_LEVELS", "RT_NO_SMALL_SCENE"):
+    switches = ("RT_NO_SMALL_LEVEL0", "RT_NO_SMALL_SCENE", "RT_NO_INLINE_TRANSMIT", "RT_NO_SELF_REPORT", "RT_NO_FUSED_LEVELS")
+    for var in switches:
         monkeypatch.delenv(var, raising=False)
     a = sc.render(W, H, seed=5, **kw)
     st = dict(sc.last_stats)
-    assert st["levels"] > 1
-    for var in ("RT_NO_SMALL_SCENE", "RT_NO_FUSED_LEVELS"):
+    assert st["levels"] > 1 or name in "cjkm"
+    for var in switches:
         monkeypatch.setenv(var, "1")
         b = sc.render(W, H, seed=5, **kw)
         assert (st["rays_nearest"], st["rays_shadow"], st["levels"]) == (sc.last_stats["rays_nearest"], sc.last_stats["rays_shadow"], sc.last_stats["levels"]), var

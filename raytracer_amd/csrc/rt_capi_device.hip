@@ -119,7 +119,7 @@ struct rt_scene {
 	RtTexFix texFix(const Lane& ln) const { return RtTexFix{ texelFix ? ln.texRec : nullptr, texHeads, texCap, &ln.ctr->texrec_count }; }
 	uint32_t qcap = 0;
 	int maxBlocks = 2048;            // grid cap of the persistent kernels
-	bool transmitAnalytic = false;   // no CSG object and no triangle of the scene transmits: exit searches are one analytic test per internal reflection (k_level does them inline)
+	bool transmitAnalytic = false;   // the scene has no CSG object and no triangle of it transmits: exit searches are one analytic test per internal reflection (k_level does them inline)
 	RtSmallScene small;              // the scene's walk / shading arrays as one blob for k_level's LDS copy (small scenes only)
 	int maxBlocksPacketNear = 2048;  // ... of the nearest-hit packet kernel (see rt_scene_upload)
 	int maxBlocksPacketShadow = 2048;   // ... and of the shadow packet kernels (one light per packet / two)
@@ -1201,7 +1201,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 		if (kr[0] != 0 || kr[1] != 0 || kr[2] != 0) sc->hasReflective = true;
 	}
 
-	sc->transmitAnalytic = sc->hasTransmissive;
+	sc->transmitAnalytic = sc->hasTransmissive && s->n_csgs == 0;   // (the CSG variants of k_level keep their exit searches in k_transmit whatever transmits)
 	for (int32_t i = 0; i < s->n_csgs && sc->transmitAnalytic; i++) { const float* kt = s->materials[s->csgs[i].mat].transmissive; if (kt[0] != 0 || kt[1] != 0 || kt[2] != 0) sc->transmitAnalytic = false; }
 	for (int64_t i = 0; i < s->n_tris && sc->transmitAnalytic; i++) { const float* kt = s->materials[s->tris[i].mat].transmissive; if (kt[0] != 0 || kt[1] != 0 || kt[2] != 0) sc->transmitAnalytic = false; }
 	for (int64_t i = 0; i < s->n_tris && !sc->texelFix; i++) {

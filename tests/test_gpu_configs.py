@@ -5,6 +5,7 @@ reference at 256x144 (tests/golden/ref_c2_224.npz); whole 1080p frames are beyon
     the two traversal forms (packets for camera rays, per-lane walks for caller-supplied rays) give bit-identical images,
   * ray counts equal to the oracle's BVH::findNearest / BVH::calcShadow counts on a reduced frame."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -581,6 +582,33 @@ def test_one_launch_per_deeper_level_equals_the_four_kernel_form(tmp_path, monke
         monkeypatch.delenv(var)
     if name in ("c3", "c2mirror", "c4mirror"):
         sc.close()
+
+
+@pytest.mark.parametrize("seed,n_objects,analytic", [(3, 4, False), (6, 14, False), (4, 4, True), (5, 8, True), (14, 14, True), (7, 40, True)])
+def test_one_launch_levels_on_random_scenes_vs_oracle(tmp_path, monkeypatch, seed, n_objects, analytic):
+    """k_level on random scenes of every primitive, material and light kind (tools/fuzz_levels.py: the textured meshes non-reflective, so
+    that no texel records switch it off; `analytic`: no CSG objects and opaque meshes, so exit searches run inline and the kernel reports
+    its own counts): the frame against the oracle -- both ray counts equal, 8-bit RGB within 1 -- and against the four-kernel form."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_levels", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_levels.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    path, _ = fz.scene_for(str(tmp_path), seed, n_objects, analytic)
+    flat = rt.FlatScene.from_json(path)
+    sc = rt.Scene(flat, 0)
+    W, H = 160, 90
+    cam = rt.Camera(flat.fov, W, H, eye=(0, 1.0, 1.5), rot_x=-0.2)
+    monkeypatch.delenv("RT_NO_FUSED_LEVELS", raising=False)
+    img = sc.render(W, H, camera=cam, max_depth=6, seed=7)
+    st = dict(sc.last_stats)
+    ref, nn, ns = oracle.render(flat, cam, W, H, max_depth=6, seed=7, threads=8)
+    assert (st["rays_nearest"], st["rays_shadow"]) == (nn, ns)
+    assert np.abs(rgb8(img).astype(int) - rgb8(ref).astype(int)).max() <= 1
+    monkeypatch.setenv("RT_NO_FUSED_LEVELS", "1")
+    old = sc.render(W, H, camera=cam, max_depth=6, seed=7)
+    assert (sc.last_stats["rays_nearest"], sc.last_stats["rays_shadow"]) == (nn, ns)
+    assert np.abs(img - old).max() < 1e-6      # (bit-identical but for the order in which a shadow ray multiplies three or more transmissive occluders)
+    sc.close()
 
 
 @pytest.mark.parametrize("samples", [64, 24])

@@ -860,7 +860,7 @@ struct Run {
 				// Level 0 of a SMALL scene's frame goes the same way (RT_NO_SMALL_LEVEL0: through the packet kernels): with the scene in LDS a
 				// camera ray's walk is a few hundred instructions, while the persistent packet kernels, built for trees of 10^5 triangles, take
 				// 60 us a launch whatever the scene (their launch tails; measured on the bundled scenes).
-				const bool smallLevel0 = lv == 0 && src.camera && !src.outHit && sc->small.blob && aaSq <= 2 && getenv("RT_NO_SMALL_LEVEL0") == nullptr && getenv("RT_NO_SMALL_SCENE") == nullptr;
+				const bool smallLevel0 = lv == 0 && src.camera && !src.outHit && sc->small.blob && aaSq <= envU32("RT_SMALL_LEVEL0_MAX_SPP", 4) && getenv("RT_NO_SMALL_LEVEL0") == nullptr && getenv("RT_NO_SMALL_SCENE") == nullptr;
 				const bool fused = ((!packets && lv > 0) || smallLevel0) && !sc->texelFix && getenv("RT_NO_FUSED_LEVELS") == nullptr;
 				// ... and the exit searches of transmitted rays as well where they are analytic (no CSG object, no triangle transmits): such a
 				// level, like one of a scene without transmission, is a single launch that also reports its counts

@@ -9,6 +9,7 @@ import raytracer_amd as rt
 from raytracer_amd import scenes
 
 D = int(os.environ.get("INFLIGHT", "3"))
+AA = int(os.environ.get("AA", "1"))   # AA x AA samples per pixel
 
 
 def run(name, flat, W, H, max_depth=16, eye=(0, 0, 0), rot_x=0.0, reps=20):
@@ -16,17 +17,17 @@ def run(name, flat, W, H, max_depth=16, eye=(0, 0, 0), rot_x=0.0, reps=20):
     cam = rt.Camera(flat.fov, W, H, eye=eye, rot_x=rot_x)
     bufs = [torch.zeros(H, W, 3, device="cuda") for _ in range(D)]
     for _ in range(2):
-        st = sc.render_into(bufs[0].data_ptr(), W, H, camera=cam, max_depth=max_depth)
+        st = sc.render_into(bufs[0].data_ptr(), W, H, camera=cam, max_depth=max_depth, aa=(AA, AA))
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps):
-        st = sc.render_into(bufs[0].data_ptr(), W, H, camera=cam, max_depth=max_depth)
+        st = sc.render_into(bufs[0].data_ptr(), W, H, camera=cam, max_depth=max_depth, aa=(AA, AA))
     torch.cuda.synchronize(); alone = (time.perf_counter() - t0) / reps
     pend, n = [], D * reps
     t0 = time.perf_counter()
     for i in range(n):
         if len(pend) == D:
             sc.render_wait(pend.pop(0))
-        pend.append(sc.render_submit(bufs[i % D].data_ptr(), W, H, camera=cam, max_depth=max_depth))
+        pend.append(sc.render_submit(bufs[i % D].data_ptr(), W, H, camera=cam, max_depth=max_depth, aa=(AA, AA)))
     for t in pend:
         sc.render_wait(t)
     torch.cuda.synchronize(); piped = (time.perf_counter() - t0) / n

@@ -302,6 +302,10 @@ def roofline_block(runner, flat):
                     "wave_wait_frac": round(k["SQ_WAIT_ANY"] / wc, 3) if wc else None,
                     "wave_issue_stall_frac": round(k["SQ_WAIT_INST_ANY"] / wc, 3) if wc else None,
                     "wave_active_frac": round(k["SQ_ACTIVE_INST_ANY"] / wc, 3) if wc else None,
+                    # the profiler's own VALUBusy: quad-cycles in which a SIMD had a vector instruction in flight (SQ_ACTIVE_INST_VALU x 4 cycles)
+                    # over the SIMD-cycles of the launch -- the counter books about one quad-cycle per wave64 instruction, i.e. twice the 2 cycles
+                    # `frac` prices an instruction at, so this reads about twice `frac`; the truth for this instruction mix lies between the two
+                    "valu_busy_frac": round(k["SQ_ACTIVE_INST_VALU"] * 4 / (SIMDS * ms * 1e-3 * CLOCK_GHZ * 1e9), 4) if k.get("SQ_ACTIVE_INST_VALU") else None,
                     "counter_launch_ms": round(k["GRBM_GUI_ACTIVE"] / 8 / (CLOCK_GHZ * 1e6), 4) if k.get("GRBM_GUI_ACTIVE") else None,
                     "traffic": traffic,
                     "hbm_achieved_gbs": round(traffic / (ms * 1e-3) / 1e9, 1) if traffic else None,
@@ -312,6 +316,7 @@ def roofline_block(runner, flat):
                     "counters_from": os.path.relpath(os.path.abspath(PMC_FILE), ROOT)})
         # the whole step against the same two ceilings: every kernel's instructions and HBM bytes over the pipelined frame time
         out["_step_valu"] = sum(v.get("SQ_INSTS_VALU", 0) * v.get("launches_per_frame", 1) for v in kernels.values())
+        out["_step_valu_busy"] = sum(v.get("SQ_ACTIVE_INST_VALU", 0) * v.get("launches_per_frame", 1) for v in kernels.values())
         out["_step_traffic"] = sum((v.get("traffic_bytes_per_launch") or 0) * v.get("launches_per_frame", 1) for v in kernels.values())
     else:
         out["counters_missing"] = why or f"{kname} is not in the counter file"
@@ -482,10 +487,11 @@ def main():
     if rank == 0:
         value = rays / elapsed / 1e6
         if roofline and roofline.get("_step_valu") is not None:
-            sv, stf = roofline.pop("_step_valu"), roofline.pop("_step_traffic")
+            sv, stf, svb = roofline.pop("_step_valu"), roofline.pop("_step_traffic"), roofline.pop("_step_valu_busy", 0)
             ms_step = elapsed / args.steps * 1e3
             roofline["step_check"] = {"note": "all kernels of a frame over the pipelined frame time (N = 1 only: the counters are one GPU's)",
                                       "valu_insts_per_step": int(sv), "valu_frac": round(sv / (ms_step * 1e-3) / 1e9 / VALU_PEAK_GIPS, 4) if world == 1 else None,
+                                      "valu_busy_frac": round(svb * 4 / (SIMDS * ms_step * 1e-3 * CLOCK_GHZ * 1e9), 4) if world == 1 and svb else None,
                                       "hbm_bytes_per_step": int(stf), "hbm_frac": round(stf / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None}
         out = {
             "metric": "Mrays/sec (primary+secondary) at 1080p", "value": round(value, 2), "unit": "Mrays/s",

@@ -78,6 +78,8 @@ def config_block(root, cfg):
             if "SQ_INSTS_SALU" in mean:
                 e["salu_per_valu"] = round(mean["SQ_INSTS_SALU"] / max(valu, 1), 3)
                 e["salu_plus_branch_per_valu"] = round((mean["SQ_INSTS_SALU"] + mean.get("SQ_INSTS_BRANCH", 0)) / max(valu, 1), 3)
+            if mean.get("SQ_ACTIVE_INST_VALU"):   # the profiler's VALUBusy: quad-cycles with a vector instruction in flight x 4 over the launch's SIMD-cycles
+                e["valu_busy_frac"] = round(mean["SQ_ACTIVE_INST_VALU"] * 4 / (SIMDS * avg * CLOCK_GHZ), 4)
             if "SQ_THREAD_CYCLES_VALU" in mean and "SQ_ACTIVE_INST_VALU" in mean and mean["SQ_ACTIVE_INST_VALU"]:
                 # thread-cycles per active VALU quad-cycle: 64 lanes busy for a whole instruction = 16 per quad-cycle x 4
                 e["valu_active_lanes_of_64"] = round(mean["SQ_THREAD_CYCLES_VALU"] / mean["SQ_ACTIVE_INST_VALU"], 1)
@@ -138,6 +140,7 @@ def main(root):
                                           "valu_issue_is": f"{SIMDS} SIMDs x {CLOCK_GHZ} GHz / {VALU_ISSUE_CYCLES:g} cycles per wave64 VALU instruction"},
            "collected_with": "tools/evidence_r03.sh pmc (RT_LANES=1: one stream, one frame at a time, every kernel alone on the chip)", "configs": {}}
     lines = [f"library sources {sha}; one MI355X; kernels alone (RT_LANES=1); frac = SQ_INSTS_VALU per launch / average launch time / {VALU_PEAK_GIPS:g} G wave-instr/s",
+             "busy = SQ_ACTIVE_INST_VALU x 4 cycles / launch SIMD-cycles (the profiler's VALUBusy: about one quad-cycle booked per wave64 instruction, twice frac's 2 cycles)",
              "hbm = (FETCH_SIZE x 2 + WRITE_SIZE) per launch / launch time / 8 TB/s; L2 = TCC_HIT / (TCC_HIT + TCC_MISS); waves/SIMD = mean resident over the launch", ""]
     for cfg in ("C2", "C3", "C4", "C5"):
         if not os.path.isdir(os.path.join(root, f"pmc_{cfg}")):
@@ -147,10 +150,10 @@ def main(root):
         lines.append(f"== {cfg}: {b['command']}")
         if b["run_reported"]:
             lines.append(f"   {b['run_reported'][:200]}")
-        lines.append(f"{'kernel':52s} {'calls':>5s} {'share':>6s} {'avg us':>9s} {'VALU M':>8s} {'frac':>6s} {'S+B/V':>6s} {'wait':>5s} {'HBM MB':>8s} {'hbm':>6s} {'L2 hit':>6s} {'waves/SIMD':>10s}")
+        lines.append(f"{'kernel':52s} {'calls':>5s} {'share':>6s} {'avg us':>9s} {'VALU M':>8s} {'frac':>6s} {'busy':>6s} {'S+B/V':>6s} {'wait':>5s} {'HBM MB':>8s} {'hbm':>6s} {'L2 hit':>6s} {'waves/SIMD':>10s}")
         for e in b["kernels"]:
             lines.append(f"{e['kernel'][:52]:52s} {e['launches_in_trace']:5d} {e['share_of_kernel_time']:6.3f} {e['avg_launch_us']:9.1f} "
-                         f"{e.get('valu_insts_per_launch', 0) / 1e6:8.2f} {e.get('frac_of_valu_issue', float('nan')):6.3f} {e.get('salu_plus_branch_per_valu', float('nan')):6.2f} "
+                         f"{e.get('valu_insts_per_launch', 0) / 1e6:8.2f} {e.get('frac_of_valu_issue', float('nan')):6.3f} {e.get('valu_busy_frac', float('nan')):6.3f} {e.get('salu_plus_branch_per_valu', float('nan')):6.2f} "
                          f"{e.get('wave_wait_frac', float('nan')):5.2f} {e.get('hbm_bytes_per_launch', 0) / 1e6:8.1f} {e.get('hbm_frac', float('nan')):6.3f} "
                          f"{e.get('l2_hit_rate', float('nan')):6.3f} {e.get('mean_resident_waves_per_simd', float('nan')):10.2f}")
         lines.append("")

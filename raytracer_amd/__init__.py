@@ -11,4 +11,4 @@ include/rt_capi.h; the work is done by hand-written HIP kernels (csrc/rt_kernels
 """
 from .api import (FlatScene, Scene, Camera, View, choose_scene, current_scene, trace, shadowRay, fov, background_colour,  # noqa: F401
                   write_bmp, quantize_rgb8, device_count)
-from .capi import RtError, MAX_REFLECTIONS, RT_FLAG_COUNTERS, RT_FLAG_TIME_KERNELS  # noqa: F401
+from .capi import RtError, MAX_REFLECTIONS, RT_FLAG_COUNTERS, RT_FLAG_TIME_KERNELS, RT_FLAG_WHOLE_FRAME  # noqa: F401

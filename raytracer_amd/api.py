@@ -121,7 +121,7 @@ class Scene:
 
     def render_submit(self, frame_dev_ptr, width, height, aa=1, max_depth=capi.MAX_REFLECTIONS, seed=1, flags=0, camera=None,
                       tile_rank=0, tile_ranks=1, stream=None):
-        """Queues a frame (rt_render_submit) and returns its ticket; at most 4 may be outstanding, each into its own buffer."""
+        """Queues a frame (rt_render_submit) and returns its ticket; at most 8 may be outstanding, each into its own buffer."""
         cam = camera or self.camera(width, height)
         ax, ay = _aa(aa)
         ticket = C.c_uint64(0)

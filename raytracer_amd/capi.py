@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(_HERE, "lib", "libraytracer_amd.so")   # RT_LIB_PATH: diagnostic builds
 
 RT_OK, RT_EINVAL, RT_EIO, RT_EPARSE, RT_EHIP, RT_ENOMEM, RT_ELIMIT = 0, -1, -2, -3, -4, -5, -6
-RT_FLAG_COUNTERS, RT_FLAG_TIME_KERNELS = 1, 2
+RT_FLAG_COUNTERS, RT_FLAG_TIME_KERNELS, RT_FLAG_WHOLE_FRAME = 1, 2, 4
 MAX_REFLECTIONS = 16
 RT_STATIC_MAX_RAYS = 65536
 

@@ -24,7 +24,7 @@ namespace {
 
 #define RT_MAX_LANES 8
 #define RT_MAX_LEVELS 32   /* max_depth <= 30 is checked by the entry points: levels 0 .. 30 */
-#define RT_MAX_INFLIGHT 4
+#define RT_MAX_INFLIGHT 8
 #define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rt::set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); return RT_EHIP; } } while (0)
 
 // launch errors since the last look, with the kernel's name (rt_kernels.hip: noteLaunch), then anything else the runtime holds
@@ -126,6 +126,10 @@ struct rt_scene {
 	int maxBlocksPacketShadow2 = 2048;
 	std::vector<Lane> lanes;
 	RtAccum accum{};
+	// RT_FLAG_WHOLE_FRAME: a frame rendered on one lane owns no fixed set of pixels, so frames on different lanes may not share
+	// accumulators as shards do -- every lane has its own for such frames (24 B per pixel, allocated on first use)
+	RtAccum laneAccum[RT_MAX_LANES]{};
+	int nextWholeLane = 0;
 	// Frames are rendered asynchronously: rt_render_submit queues one shard of the frame on every lane (shard k = the
 	// tiles t of the call with t % (tile_ranks * lanes) == tile_rank + tile_ranks * k), each lane's worker thread drives
 	// its shards in submission order, and rt_render_wait joins them.  Lanes never wait for each other, so the tail of
@@ -134,6 +138,7 @@ struct rt_scene {
 		uint64_t id = 0;                 // 0 = slot free
 		rt_camera cam{};
 		int W = 0, H = 0, aaX = 1, aaY = 1, maxDepth = 0, tileRank = 0, tileRanks = 1, nShards = 1;
+		bool whole = false; int lane = 0;   // RT_FLAG_WHOLE_FRAME: the one lane that renders the frame (results in slot 0 of the per-shard arrays)
 		uint32_t seed = 0, flags = 0;
 		float* rgb = nullptr;
 		hipStream_t st = nullptr;
@@ -210,6 +215,17 @@ struct rt_scene {
 				for (int k = 0; k < j.nShards; k++) (void)hipEventSynchronize(j.evDone[k]);
 	}
 	void drain() { std::unique_lock<std::mutex> g(mtx); drainLocked(g); }
+	int ensureLaneAccum(int k, uint32_t npix) {
+		RtAccum& a = laneAccum[k];
+		if (a.npix >= npix && a.rgb) return RT_OK;
+		if (a.rgb) { (void)hipFree(a.rgb); (void)hipFree(a.nonfinite); a.rgb = nullptr; a.nonfinite = nullptr; a.npix = 0; }
+		HIPCHK(hipMalloc((void**)&a.rgb, (size_t)npix * 3 * sizeof(unsigned long long)));
+		HIPCHK(hipMalloc((void**)&a.nonfinite, (size_t)npix));
+		HIPCHK(hipMemset(a.rgb, 0, (size_t)npix * 3 * sizeof(unsigned long long)));
+		HIPCHK(hipMemset(a.nonfinite, 0, (size_t)npix));
+		a.npix = npix;
+		return RT_OK;
+	}
 	int ensureAccum(uint32_t npix) {
 		if (accum.npix >= npix && accum.rgb) return RT_OK;
 		if (accum.rgb) { (void)hipFree(accum.rgb); (void)hipFree(accum.nonfinite); accum.rgb = nullptr; accum.nonfinite = nullptr; accum.npix = 0; }
@@ -693,6 +709,8 @@ struct Run {
 	RtPick pick{ nullptr, nullptr, 0 };   // rt_trace_pick: where the narration's events go
 	uint32_t texRecords = 0;               // RtTexFix records the current batch has left so far
 	uint32_t stateCases = 0;               // failed exit searches since begin() (the lane's counter is cumulative over the call's batches)
+	RtAccum acc{};                         // the accumulators this run adds into: the scene's shared ones, or the lane's own (RT_FLAG_WHOLE_FRAME); set by use()
+	Run& use(const RtAccum& a) { acc = a; return *this; }
 
 	// Which traversal form a level uses.  Level 0 of a frame (and its shadow rays) is coherent by construction: 64
 	// consecutive queue slots are an 8x8 pixel block.  Deeper levels and caller-supplied rays are walked per lane.
@@ -729,9 +747,9 @@ struct Run {
 			if (timeK) HIPCHK(hipEventRecord(ln->ev[2], st));
 			rtk_intersect(st, sc->dev, sc->hasCsg, count, coherent(level), coherent(level) ? sc->maxBlocksPacketNear : sc->maxBlocks, ln->ray[cur], n, ln->hitq, ln->ctr);
 			if (timeK) HIPCHK(hipEventRecord(ln->ev[3], st));
-			rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, n, ln->ray[cur ^ 1], ln->surfq, ln->transq, ln->ctr, sc->accum, aaSq, maxDepth,
+			rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, n, ln->ray[cur ^ 1], ln->surfq, ln->transq, ln->ctr, acc, aaSq, maxDepth,
 			          sc->shadowRaysPerSurface > 0, level == 0 ? src.outHit : nullptr, src.outId, src.outT, pick, sc->texFix(*ln));
-			if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, n, ln->ray[cur ^ 1], ln->ctr, &ln->ctr->state_cases, sc->accum, aaSq, maxDepth, pick);
+			if (sc->hasTransmissive) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, n, ln->ray[cur ^ 1], ln->ctr, &ln->ctr->state_cases, acc, aaSq, maxDepth, pick);
 			// Level 0 of a frame lit by point-type lights only: the shadow packets are queued before the host has seen the
 			// counts (the kernels read them on the device), and the host waits for the count read-back while they run --
 			// the lane's stream never idles through a host round trip.
@@ -740,7 +758,7 @@ struct Run {
 				if (int rcL = launchesOk()) return rcL;
 				HIPCHK(hipMemcpyAsync(ln->ctrHost, ln->ctr, sizeof(RtCounters), hipMemcpyDeviceToHost, st));
 				HIPCHK(hipEventRecord(ln->ev[4], st));
-				rtk_shadow_point(st, sc->dev, sc->hasCsg, false, true, sc->maxBlocksPacketShadow, ln->surfq, n, sc->pointLights, sc->nPointLights, sc->accum, aaSq, ln->ctr, true, sc->maxBlocksPacketShadow2);
+				rtk_shadow_point(st, sc->dev, sc->hasCsg, false, true, sc->maxBlocksPacketShadow, ln->surfq, n, sc->pointLights, sc->nPointLights, acc, aaSq, ln->ctr, true, sc->maxBlocksPacketShadow2);
 				HIPCHK(hipEventSynchronize(ln->ev[4]));
 			} else
 			if (int rc = syncCounters()) return rc;
@@ -759,8 +777,8 @@ struct Run {
 			if (early) shadowRays += (uint64_t)nsurf * sc->shadowRaysPerSurface;
 			else if (nsurf > 0 && sc->shadowRaysPerSurface > 0) {
 				if (timeK) HIPCHK(hipEventRecord(ln->ev[4], st));
-				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, coherent(level), coherent(level) ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nsurf, sc->pointLights, sc->nPointLights, sc->accum, aaSq, ln->ctr, false, sc->maxBlocksPacketShadow2);
-				for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, sc->nCsg, count, ln->surfq, nsurf, al.first, al.second, seed, sc->accum, aaSq, ln->ctr);
+				if (sc->nPointLights) rtk_shadow_point(st, sc->dev, sc->hasCsg, count, coherent(level), coherent(level) ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nsurf, sc->pointLights, sc->nPointLights, acc, aaSq, ln->ctr, false, sc->maxBlocksPacketShadow2);
+				for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, sc->nCsg, count, ln->surfq, nsurf, al.first, al.second, seed, acc, aaSq, ln->ctr);
 				if (timeK) { HIPCHK(hipEventRecord(ln->ev[5], st)); shadowPending = true; }
 				shadowRays += (uint64_t)nsurf * sc->shadowRaysPerSurface;
 			}
@@ -773,7 +791,7 @@ struct Run {
 			HIPCHK(hipEventElapsedTime(&ms, ln->ev[4], ln->ev[5])); stats.shadow_ms += ms;
 		}
 		// hits on reflective textured triangles that their own reflected ray's subtree came back to: lit with the last hit's texel
-		rtk_texel_fix(st, sc->dev, sc->hasCsg, sc->texFix(*ln), texRecords, ln->ctr, sc->accum, aaSq, seed, true);
+		rtk_texel_fix(st, sc->dev, sc->hasCsg, sc->texFix(*ln), texRecords, ln->ctr, acc, aaSq, seed, true);
 		stats.rays_nearest += nearRays; stats.rays_shadow += shadowRays; stats.levels = std::max<uint64_t>(stats.levels, nLevels);
 		return RT_OK;
 	}
@@ -867,19 +885,19 @@ struct Run {
 				const bool inlineX = fused && sc->hasTransmissive && sc->transmitAnalytic && getenv("RT_NO_INLINE_TRANSMIT") == nullptr;
 				const bool selfReport = fused && (!sc->hasTransmissive || inlineX) && getenv("RT_NO_SELF_REPORT") == nullptr;
 				seqOf[lv] = ++ln->reportSeq ? ln->reportSeq : ++ln->reportSeq;   // (never 0)
-				if (fused) rtk_level(st, sc->dev, sc->small, sc->hasCsg, inlineX, ln->ray[cur], nb, nDev, ln->ray[cur ^ 1], ln->surfq, ln->transq, &L[lv], sc->accum, aaSq, maxDepth,
+				if (fused) rtk_level(st, sc->dev, sc->small, sc->hasCsg, inlineX, ln->ray[cur], nb, nDev, ln->ray[cur ^ 1], ln->surfq, ln->transq, &L[lv], acc, aaSq, maxDepth,
 				                     !shadows ? 0 : sc->areaLights.empty() ? 1 : 2, sc->pointLights, (uint32_t)sc->nPointLights,
 				                     sc->hasTransmissive ? &ln->ctr->state_cases : nullptr, selfReport ? ln->reportDev + lv : nullptr, seqOf[lv]);
 				else {
 				rtk_intersect(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketNear : sc->maxBlocks, ln->ray[cur], nb, ln->hitq, &L[lv], nDev);
-				rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, nb, ln->ray[cur ^ 1], ln->surfq, ln->transq, &L[lv], sc->accum, aaSq, maxDepth,
+				rtk_shade(st, sc->dev, sc->hasCsg, ln->ray[cur], ln->hitq, nb, ln->ray[cur ^ 1], ln->surfq, ln->transq, &L[lv], acc, aaSq, maxDepth,
 				          shadows, lv == 0 ? src.outHit : nullptr, src.outId, src.outT, pick, sc->texFix(*ln), nDev);
 				}
-				if (sc->hasTransmissive && !inlineX) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, nb, ln->ray[cur ^ 1], &L[lv], &ln->ctr->state_cases, sc->accum, aaSq, maxDepth, pick);
+				if (sc->hasTransmissive && !inlineX) rtk_transmit(st, sc->dev, sc->hasCsg, ln->transq, nb, ln->ray[cur ^ 1], &L[lv], &ln->ctr->state_cases, acc, aaSq, maxDepth, pick);
 				if (!selfReport) rtk_publish(st, &L[lv], sc->texelFix ? &ln->ctr->texrec_count : nullptr, sc->hasTransmissive ? &ln->ctr->state_cases : nullptr, ln->reportDev + lv, seqOf[lv]);
 				if (shadows) {
-					if (sc->nPointLights && !fused) rtk_shadow_point(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nb, sc->pointLights, sc->nPointLights, sc->accum, aaSq, &L[lv], true, sc->maxBlocksPacketShadow2);
-					for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, sc->nCsg, false, ln->surfq, nb, al.first, al.second, seed, sc->accum, aaSq, &L[lv], true);
+					if (sc->nPointLights && !fused) rtk_shadow_point(st, sc->dev, sc->hasCsg, false, packets, packets ? sc->maxBlocksPacketShadow : sc->maxBlocks, ln->surfq, nb, sc->pointLights, sc->nPointLights, acc, aaSq, &L[lv], true, sc->maxBlocksPacketShadow2);
+					for (auto& al : sc->areaLights) rtk_shadow_area(st, sc->dev, sc->hasCsg, sc->nCsg, false, ln->surfq, nb, al.first, al.second, seed, acc, aaSq, &L[lv], true);
 				}
 				if (int rcL = launchesOk()) return rcL;
 				cur ^= 1;
@@ -909,7 +927,7 @@ struct Run {
 			return 1;
 		}
 		// hits on reflective textured triangles that their own reflected ray's subtree came back to: lit with the last hit's texel
-		rtk_texel_fix(st, sc->dev, sc->hasCsg, sc->texFix(*ln), texRecords, ln->ctr, sc->accum, aaSq, seed, true);
+		rtk_texel_fix(st, sc->dev, sc->hasCsg, sc->texFix(*ln), texRecords, ln->ctr, acc, aaSq, seed, true);
 		stats.rays_nearest += nearRays; stats.rays_shadow += shadowRays; stats.levels = std::max<uint64_t>(stats.levels, nLevels);
 		return RT_OK;
 	}
@@ -922,9 +940,9 @@ struct Run {
 		stats = saved;
 		stats.batch_splits++;
 		HIPCHK(hipMemsetAsync(&ln->ctr->overflow, 0, sizeof(uint32_t), st));
-		rtk_texel_fix(st, sc->dev, sc->hasCsg, sc->texFix(*ln), texRecords, ln->ctr, sc->accum, aaSq, seed, false);   // drop the discarded batch's records
+		rtk_texel_fix(st, sc->dev, sc->hasCsg, sc->texFix(*ln), texRecords, ln->ctr, acc, aaSq, seed, false);   // drop the discarded batch's records
 		// clear this batch's pixels (resolve with no destination only zeroes the accumulators)
-		rtk_resolve(st, sc->accum, src.W, src.H, src.tileRank, src.tileRanks, r0 / aaSq, cnt / aaSq, aaSq, src.camera ? 0 : 1, nullptr);
+		rtk_resolve(st, acc, src.W, src.H, src.tileRank, src.tileRanks, r0 / aaSq, cnt / aaSq, aaSq, src.camera ? 0 : 1, nullptr);
 		if (cnt <= aaSq) { rt::set_error("ray queue too small for the ray tree of a single pixel (raise RT_QUEUE_RAYS)"); return RT_ELIMIT; }
 		const uint32_t half = std::max(aaSq, (cnt / 2 / aaSq) * aaSq);
 		if (int r1 = batch(r0, half)) return r1;
@@ -1003,20 +1021,23 @@ int renderShard(rt_scene* sc, rt_scene::Job* job, int k) {
 	}
 	HIPCHK(hipStreamWaitEvent(st, job->evStart, 0));
 	if (int rc = begin(sc, ln, st, job->flags)) return rc;
-	const int vr = job->tileRank + job->tileRanks * k, vn = job->tileRanks * job->nShards;
+	// (a whole frame on this lane: the call's own tile split, the lane's own accumulators, results in slot 0)
+	const int slot = job->whole ? 0 : k;
+	const int vr = job->whole ? job->tileRank : job->tileRank + job->tileRanks * k, vn = job->whole ? job->tileRanks : job->tileRanks * job->nShards;
 	const uint32_t aaSq = (uint32_t)(job->aaX * job->aaY);
 	Run run{ sc, ln, st, {}, job->maxDepth, job->seed, job->flags, aaSq };
+	run.use(job->whole ? sc->laneAccum[k] : sc->accum);
 	run.src.camera = true; run.src.cam = job->cam; run.src.W = job->W; run.src.H = job->H; run.src.aaX = job->aaX; run.src.aaY = job->aaY;
 	run.src.tileRank = vr; run.src.tileRanks = vn;
 	const uint64_t localPix = (uint64_t)localTiles(job->W, job->H, vr, vn) * 256;
 	if (int rc = run.all(localPix * aaSq)) return rc;
-	rtk_resolve(st, sc->accum, job->W, job->H, vr, vn, 0, (uint32_t)localPix, aaSq, 0, job->rgb);
+	rtk_resolve(st, run.acc, job->W, job->H, vr, vn, 0, (uint32_t)localPix, aaSq, 0, job->rgb);
 	// the padding slots of partial edge tiles went through the first level as inactive lanes: they are not rays
 	run.stats.rays_nearest -= (localPix - (uint64_t)ownedPixels(job->W, job->H, vr, vn)) * aaSq;
 	if (int rcL = launchesOk()) return rcL;
-	HIPCHK(hipEventRecord(job->evDone[k], st));
-	if (job->flags & (RT_FLAG_COUNTERS | RT_FLAG_TIME_KERNELS)) { if (int rc = finish(sc, ln, st, run, &job->part[k])) return rc; }
-	else job->part[k] = run.stats;
+	HIPCHK(hipEventRecord(job->evDone[slot], st));
+	if (job->flags & (RT_FLAG_COUNTERS | RT_FLAG_TIME_KERNELS)) { if (int rc = finish(sc, ln, st, run, &job->part[slot])) return rc; }
+	else job->part[slot] = run.stats;
 	return RT_OK;
 }
 
@@ -1031,14 +1052,15 @@ void laneWorker(rt_scene* sc, int k) {
 			job = sc->laneQueue[k].front();
 			sc->laneQueue[k].pop_front();
 		}
-		if (k < job->nShards) {
+		if (job->whole ? k == job->lane : k < job->nShards) {
+			const int slot = job->whole ? 0 : k;
 			static const bool dbg = getenv("RT_DEBUG_LANES") != nullptr;
 			static const auto epoch = std::chrono::steady_clock::now();
 			const double t0 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - epoch).count();
-			job->rc[k] = renderShard(sc, job, k);
-			if (job->rc[k]) job->err[k] = rt_last_error();
+			job->rc[slot] = renderShard(sc, job, k);
+			if (job->rc[slot]) job->err[slot] = rt_last_error();
 			if (dbg) {
-				(void)hipEventSynchronize(job->evDone[k]);
+				(void)hipEventSynchronize(job->evDone[slot]);
 				const double t1 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - epoch).count();
 				fprintf(stderr, "[lane %d] job %llu: %.0f .. %.0f us (%.0f)\n", k, (unsigned long long)job->id, t0, t1, t1 - t0);
 			}
@@ -1285,6 +1307,7 @@ void rt_scene_free(rt_scene* sc) {
 	for (void* p : sc->allocs) (void)hipFree(p);
 	if (sc->accum.rgb) (void)hipFree(sc->accum.rgb);
 	if (sc->accum.nonfinite) (void)hipFree(sc->accum.nonfinite);
+	for (RtAccum& a : sc->laneAccum) { if (a.rgb) (void)hipFree(a.rgb); if (a.nonfinite) (void)hipFree(a.nonfinite); }
 	if (sc->texHeads) (void)hipFree(sc->texHeads);
 	for (auto& ln : sc->lanes) {
 		if (ln.ctrHost) (void)hipHostFree(ln.ctrHost);
@@ -1315,6 +1338,9 @@ int rt_render_submit(rt_scene* sc, const rt_camera* camera, int width, int heigh
 	const int64_t tiles = localTiles(width, height, tile_rank, tile_ranks);
 	int nShards = (int)sc->lanes.size();
 	if (exclusive || tiles < 64 * nShards) nShards = 1;
+	// RT_FLAG_WHOLE_FRAME: the frame on one lane (not for scenes that keep texel records: their per-pixel lists are shared like the accumulators)
+	const bool whole = (flags & RT_FLAG_WHOLE_FRAME) != 0 && !exclusive && !sc->texelFix && sc->lanes.size() > 1;
+	if (whole) nShards = 1;
 
 	std::unique_lock<std::mutex> g(sc->mtx);
 	// any free slot (tickets may be waited for in any order); the ticket carries its slot: ticket % RT_MAX_INFLIGHT
@@ -1323,15 +1349,23 @@ int rt_render_submit(rt_scene* sc, const rt_camera* camera, int width, int heigh
 	if (!job) { rt::set_error("rt_render_submit: too many frames in flight (wait for an earlier ticket first)"); return RT_EINVAL; }
 	const uint64_t newTicket = sc->nextId * RT_MAX_INFLIGHT + (uint64_t)(job - sc->jobs);
 	// Shards of consecutive frames may overlap only if they own the same pixels of the shared accumulators
-	bool compatible = !exclusive && sc->accum.npix >= (uint32_t)(width * height) && sc->accum.rgb;
+	// Whole frames go to the lanes with streams of their own, 1 .. n-1, in turn.  Lane 0 works on the caller's stream, and rt_render_wait makes that
+	// stream wait for every frame it retires (work the caller queues afterwards must see the frame): a whole frame on lane 0 would sit behind
+	// the other lanes' frames.  With the caller's stream carrying only those events the process stays within its four hardware queues.
+	const int lane = whole ? 1 + sc->nextWholeLane++ % ((int)sc->lanes.size() - 1) : 0;
+	// (a whole frame has its lane's accumulators to itself -- the lane's stream orders it behind that lane's earlier work -- so it overlaps
+	// with anything unless those accumulators must grow; sharded frames overlap with each other as before and with whole frames freely)
+	bool compatible = !exclusive && (whole ? sc->laneAccum[lane].npix >= (uint32_t)(width * height) && sc->laneAccum[lane].rgb != nullptr
+	                                       : sc->accum.npix >= (uint32_t)(width * height) && sc->accum.rgb);
 	for (const rt_scene::Job& j : sc->jobs)
-		if (j.id && j.remaining > 0 &&
-		    (j.W != width || j.H != height || j.tileRank != tile_rank || j.tileRanks != tile_ranks || j.nShards != nShards || (j.flags & (RT_FLAG_COUNTERS | RT_FLAG_TIME_KERNELS))))
+		if (j.id && j.remaining > 0 && ((j.flags & (RT_FLAG_COUNTERS | RT_FLAG_TIME_KERNELS)) ||
+		    (!whole && !j.whole && (j.W != width || j.H != height || j.tileRank != tile_rank || j.tileRanks != tile_ranks || j.nShards != nShards))))
 			compatible = false;
 	if (!compatible) sc->drainLocked(g);
-	if (int rc = sc->ensureAccum((uint32_t)(width * height))) return rc;
+	if (int rc = whole ? sc->ensureLaneAccum(lane, (uint32_t)(width * height)) : sc->ensureAccum((uint32_t)(width * height))) return rc;
 	job->cam = *camera; job->W = width; job->H = height; job->aaX = aa_x; job->aaY = aa_y; job->maxDepth = max_depth;
 	job->tileRank = tile_rank; job->tileRanks = tile_ranks; job->nShards = nShards; job->seed = seed; job->flags = flags; job->rgb = rgb_dev; job->st = st;
+	job->whole = whole; job->lane = lane;
 	HIPCHK(hipEventRecord(job->evStart, st));   // the lanes start after whatever the caller queued on its stream before this call
 	job->id = newTicket;
 	sc->nextId++;
@@ -1426,6 +1460,7 @@ int rt_trace_batch(rt_scene* sc, const float* e, const float* s, size_t n, int m
 	if (int rc = begin(sc, ln, st, flags)) return rc;
 	if (int rc = sc->ensureAccum((uint32_t)n)) return rc;
 	Run run{ sc, ln, st, {}, max_depth, seed, flags, 1u };
+	run.use(sc->accum);
 	run.src.a = de.as<float>(); run.src.b = ds.as<float>();
 	run.src.outHit = dhit.as<uint8_t>(); run.src.outId = did.as<int32_t>(); run.src.outT = dt.as<float>();
 	if (int rc = run.all(n)) return rc;
@@ -1460,6 +1495,7 @@ int rt_trace_pick(rt_scene* sc, const float* e, const float* s, int max_depth, u
 	if (int rc = begin(sc, ln, st, 0)) return rc;
 	if (int rc = sc->ensureAccum(1)) return rc;
 	Run run{ sc, ln, st, {}, max_depth, seed, 0u, 1u };
+	run.use(sc->accum);
 	run.src.a = de.as<float>(); run.src.b = ds.as<float>();
 	run.src.outHit = dhit.as<uint8_t>(); run.src.outId = did.as<int32_t>(); run.src.outT = dt.as<float>();
 	run.pick = RtPick{ dev.as<rt_pick_event>(), dcount.as<uint32_t>(), (uint32_t)cap };
@@ -1493,6 +1529,7 @@ int rt_intersect_batch(rt_scene* sc, const float* e, const float* d, size_t n, u
 	rt_scene::Lane* ln = &sc->lanes[0];
 	if (int rc = begin(sc, ln, st, flags)) return rc;
 	Run run{ sc, ln, st, {}, 0, 0, flags, 1u };
+	run.use(sc->accum);
 	for (size_t c0 = 0; c0 < n; c0 += sc->qcap) {
 		const uint32_t cnt = (uint32_t)std::min<size_t>(sc->qcap, n - c0);
 		HIPCHK(hipMemsetAsync(ln->ctr, 0, RT_COUNTER_RESET_BYTES, st));
@@ -1559,6 +1596,7 @@ int rt_shadow_batch(rt_scene* sc, const float* point, const float* light_pos, si
 	rt_scene::Lane* ln = &sc->lanes[0];
 	if (int rc = begin(sc, ln, st, flags)) return rc;
 	Run run{ sc, ln, st, {}, 0, 0, flags & ~RT_FLAG_COUNTERS, 1u };
+	run.use(sc->accum);
 	rtk_shadow_query(st, sc->dev, sc->hasCsg, dp.as<float>(), dl.as<float>(), (uint32_t)n, dlit.as<uint8_t>(), dsh.as<float>());
 	run.stats.rays_shadow = n;
 	if (int rc = finish(sc, ln, st, run, stats)) return rc;

@@ -68,17 +68,17 @@ def test_ticket_rules(c2):
     flat, sc = c2
     W, H = 480, 270
     cam = rt.Camera(flat.fov, W, H, eye=(0, 1.5, 1.0), rot_x=-0.3)
-    bufs = [torch.zeros(H, W, 3, device="cuda") for _ in range(5)]
-    tickets = [sc.render_submit(bufs[i].data_ptr(), W, H, camera=cam) for i in range(4)]
+    bufs = [torch.zeros(H, W, 3, device="cuda") for _ in range(9)]
+    tickets = [sc.render_submit(bufs[i].data_ptr(), W, H, camera=cam) for i in range(8)]
     with pytest.raises(RtError):
-        sc.render_submit(bufs[4].data_ptr(), W, H, camera=cam)            # a fifth frame in flight
+        sc.render_submit(bufs[8].data_ptr(), W, H, camera=cam)            # a ninth frame in flight
     for t in tickets:
         sc.render_wait(t)
     with pytest.raises(RtError):
         sc.render_wait(tickets[0])                                        # waited for already
     with pytest.raises(RtError):
         sc.render_wait(12345)
-    assert all(torch.equal(bufs[0], b) for b in bufs[1:4])
+    assert all(torch.equal(bufs[0], b) for b in bufs[1:8])
 
 
 def test_handle_freed_with_frames_in_flight(c2):
@@ -97,16 +97,16 @@ def test_handle_freed_with_frames_in_flight(c2):
 
 
 def test_tickets_waited_out_of_order_free_their_slots(c2):
-    """Up to 4 tickets outstanding, waited for in any order: a slot is free as soon as ITS ticket was waited for."""
+    """Up to 8 tickets outstanding, waited for in any order: a slot is free as soon as ITS ticket was waited for."""
     flat, sc = c2
     W, H = 480, 270
     cam = rt.Camera(flat.fov, W, H, eye=(0, 1.5, 1.0), rot_x=-0.3)
-    bufs = [torch.zeros(H, W, 3, device="cuda") for _ in range(4)]
-    t = [sc.render_submit(bufs[i].data_ptr(), W, H, camera=cam) for i in range(4)]
-    for k in (1, 2, 3):
+    bufs = [torch.zeros(H, W, 3, device="cuda") for _ in range(8)]
+    t = [sc.render_submit(bufs[i].data_ptr(), W, H, camera=cam) for i in range(8)]
+    for k in range(1, 8):
         sc.render_wait(t[k])
-    more = [sc.render_submit(bufs[k].data_ptr(), W, H, camera=cam) for k in (1, 2, 3)]   # ticket t[0] is still outstanding
-    assert len(set(more + t)) == 7
+    more = [sc.render_submit(bufs[k].data_ptr(), W, H, camera=cam) for k in range(1, 8)]   # ticket t[0] is still outstanding
+    assert len(set(more + t)) == 15
     sc.render_wait(t[0])
     for m in reversed(more):
         sc.render_wait(m)
@@ -138,3 +138,40 @@ def test_other_entry_points_wait_for_the_gpu_not_only_for_the_lanes(c2):
             assert np.array_equal(got[k], want[k])
         assert np.array_equal(got["t"].view(np.uint32), want["t"].view(np.uint32))
         assert np.array_equal(got["rgb"].view(np.uint32), want["rgb"].view(np.uint32))
+
+
+@pytest.mark.parametrize("aa", [1, 2])
+def test_whole_frames_on_one_lane_equal_sharded_frames(c2, aa):
+    """RT_FLAG_WHOLE_FRAME: a frame in flight is rendered on ONE lane (its own accumulators), frames dealt to the lanes in turn, instead of
+    as a shard per lane.  Same pixels bit for bit and the same ray counts -- whole and sharded frames mixed in flight, cameras changing,
+    a tile split as a rank of a multi-GPU job would ask for, and a frame size change in the middle (the lanes' accumulators grow)."""
+    flat, sc = c2
+    jobs = []
+    for i in range(9):
+        W, H = (960, 540) if i < 6 else (640, 360)
+        cam = rt.Camera(flat.fov, W, H, eye=(0.1 * i, 1.5, 1.0 - 0.2 * i), rot_x=-0.3, rot_y=0.05 * i)
+        jobs.append((W, H, cam, (i % 3, 3) if i in (4, 5) else (0, 1)))
+    ref = []
+    for W, H, cam, (tr, trs) in jobs:
+        buf = torch.zeros(H, W, 3, device="cuda")
+        st = sc.render_into(buf.data_ptr(), W, H, camera=cam, aa=aa, tile_rank=tr, tile_ranks=trs)
+        ref.append((buf.cpu().numpy().copy(), st["rays_nearest"], st["rays_shadow"]))
+    bufs = [torch.zeros(540, 960, 3, device="cuda") for _ in range(3)]
+    pending, got = [], []
+
+    def retire():
+        t, b, W, H = pending.pop(0)
+        st = sc.render_wait(t)
+        got.append((b.view(-1)[:H * W * 3].view(H, W, 3).cpu().numpy().copy(), st["rays_nearest"], st["rays_shadow"]))
+    for i, (W, H, cam, (tr, trs)) in enumerate(jobs):
+        if len(pending) == 3:
+            retire()
+        b = bufs[i % 3]
+        b.zero_()
+        flags = 0 if i == 2 else rt.RT_FLAG_WHOLE_FRAME          # (one sharded frame in the middle of the whole ones)
+        pending.append((sc.render_submit(b.view(-1)[:H * W * 3].data_ptr(), W, H, camera=cam, aa=aa, tile_rank=tr, tile_ranks=trs, flags=flags), b, W, H))
+    while pending:
+        retire()
+    for (a, an, ash), (b, bn, bsh) in zip(ref, got):
+        assert (an, ash) == (bn, bsh)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -38,19 +38,25 @@ def gpu_time(rt, torch, flat, W, H, aa, max_depth, eye, rot_x, reps):
         st = sc.render_into(bufs[0].data_ptr(), W, H, aa=aa, camera=cam, max_depth=max_depth)
     torch.cuda.synchronize()
     alone = (time.perf_counter() - t0) / reps
-    pending = []
-    n = 3 * reps
-    t0 = time.perf_counter()
-    for i in range(n):
-        if len(pending) == 3:
-            sc.render_wait(pending.pop(0))
-        pending.append(sc.render_submit(bufs[i % 3].data_ptr(), W, H, aa=aa, camera=cam, max_depth=max_depth))
-    for t in pending:
-        sc.render_wait(t)
-    torch.cuda.synchronize()
-    piped = (time.perf_counter() - t0) / n
+    def piped_ms(flags, D):
+        while len(bufs) < D:
+            bufs.append(torch.zeros(H, W, 3, device="cuda"))
+        pending = []
+        n = D * reps
+        for rep in range(2):            # (the first pass warms the mode up: the lanes' own accumulators)
+            t0 = time.perf_counter()
+            for i in range(n):
+                if len(pending) == D:
+                    sc.render_wait(pending.pop(0))
+                pending.append(sc.render_submit(bufs[i % D].data_ptr(), W, H, aa=aa, camera=cam, max_depth=max_depth, flags=flags))
+            while pending:
+                sc.render_wait(pending.pop(0))
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    sharded = piped_ms(0, 3)                              # every frame cut into a shard per lane, three frames in flight (round 2's form)
+    whole = piped_ms(rt.RT_FLAG_WHOLE_FRAME, 6)           # whole frames dealt to the lanes, six in flight
     sc.close()
-    return alone, piped, st
+    return alone, min(sharded, whole), st, sharded, whole
 
 
 def run_all(out_path, log=print):
@@ -86,7 +92,7 @@ def run_all(out_path, log=print):
                 "counters_from": os.path.relpath(os.path.abspath(roof_path), ROOT), "source_sha": buildinfo.source_sha()}
 
     def one(name, label, flat, W, H, aa=1, max_depth=16, eye=(0.0, 0.0, 0.0), rot_x=0.0, reps=5, cpu_scale=1, cpu_aa=None, cpu_threads_only=False):
-        alone, piped, st = gpu_time(rt, torch, flat, W, H, (aa, aa), max_depth, eye, rot_x, reps)
+        alone, piped, st, sharded, whole = gpu_time(rt, torch, flat, W, H, (aa, aa), max_depth, eye, rot_x, reps)
         rays = st["rays_nearest"] + st["rays_shadow"]
         # CPU sample: same scene, camera and depth limit; resolution divided by cpu_scale per axis (and cpu_aa samples per pixel)
         cw, ch, ca = W // cpu_scale, H // cpu_scale, (aa if cpu_aa is None else cpu_aa)
@@ -110,6 +116,7 @@ def run_all(out_path, log=print):
         row = {"config": name, "workload": label, "width": W, "height": H, "samples_per_pixel": aa * aa, "max_depth": max_depth,
                "rays_per_frame": int(rays), "levels": int(st["levels"]), "batch_splits": int(st["batch_splits"]),
                "gpu_ms_per_frame": round(piped * 1e3, 4), "gpu_single_frame_ms": round(alone * 1e3, 4),
+               "gpu_ms_per_frame_sharded_3_in_flight": round(sharded * 1e3, 4), "gpu_ms_per_frame_whole_frames_6_in_flight": round(whole * 1e3, 4),
                "gpu_mrays_s": round(rays / piped / 1e6, 1), "gpu_single_frame_mrays_s": round(rays / alone / 1e6, 1),
                "cpu_mrays_s_1_thread": None if cpu1 is None else round(cpu1, 3), "cpu_mrays_s_all_threads": round(cpuN, 3), "cpu_threads": threads,
                "cpu_sample": f"{cw}x{ch}, {ca * ca} sample(s)/pixel, same scene, camera and depth limit ({nn + ns} rays in {dN:.2f} s on {threads} threads)",
@@ -117,7 +124,7 @@ def run_all(out_path, log=print):
                "gpu_over_cpu_1_thread": None if cpu1 is None else round(rays / piped / 1e6 / cpu1, 1),
                "roofline": roofline_of(name)}
         rows.append(row)
-        log(f"{name}: GPU {row['gpu_ms_per_frame']} ms/frame ({row['gpu_single_frame_ms']} alone), {rays / 1e6:.2f} Mrays, {row['gpu_mrays_s']} Mrays/s; "
+        log(f"{name}: GPU {row['gpu_ms_per_frame']} ms/frame (shards {row['gpu_ms_per_frame_sharded_3_in_flight']}, whole frames {row['gpu_ms_per_frame_whole_frames_6_in_flight']}, {row['gpu_single_frame_ms']} alone), {rays / 1e6:.2f} Mrays, {row['gpu_mrays_s']} Mrays/s; "
             f"CPU {row['cpu_mrays_s_1_thread']} / {row['cpu_mrays_s_all_threads']} Mrays/s (1 / {threads} threads); x{row['gpu_over_cpu_all_threads']}")
 
     with tempfile.TemporaryDirectory() as tmp:
@@ -143,7 +150,7 @@ def run_all(out_path, log=print):
             flat = rt.FlatScene.from_json(scenes.c5_scene(tmp, c5_grid))
             one("C5", f"{flat.info.n_tris}-triangle height field, 3840x2160, 4x4 samples/pixel", flat, 3840, 2160, aa=4, eye=(0.0, 1.5, 1.0), rot_x=-0.3,
                 reps=1, cpu_scale=8, cpu_aa=1)
-    doc = {"note": "GPU: one MI355X, frames in flight (rt_render_submit, 3 outstanding) and one frame alone (rt_render); rays = findNearest + calcShadow calls. "
+    doc = {"note": "GPU: one MI355X, frames in flight (rt_render_submit: the better of shards with 3 outstanding and whole frames, RT_FLAG_WHOLE_FRAME, with 6; both given) and one frame alone (rt_render); rays = findNearest + calcShadow calls. "
                    "CPU: oracle/restate.cpp (the reference's algorithm, one ray at a time) on this box's host cores.",
            "cpu_threads": threads, "configs": rows}
     os.makedirs(os.path.dirname(out_path), exist_ok=True)

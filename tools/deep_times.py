@@ -9,6 +9,7 @@ import raytracer_amd as rt
 from raytracer_amd import scenes
 
 D = int(os.environ.get("INFLIGHT", "3"))
+FLAGS = rt_flags = int(os.environ.get("WHOLE", "0")) * 4   # WHOLE=1: RT_FLAG_WHOLE_FRAME (use INFLIGHT=6 with it)
 AA = int(os.environ.get("AA", "1"))   # AA x AA samples per pixel
 
 
@@ -27,7 +28,7 @@ def run(name, flat, W, H, max_depth=16, eye=(0, 0, 0), rot_x=0.0, reps=20):
     for i in range(n):
         if len(pend) == D:
             sc.render_wait(pend.pop(0))
-        pend.append(sc.render_submit(bufs[i % D].data_ptr(), W, H, camera=cam, max_depth=max_depth, aa=(AA, AA)))
+        pend.append(sc.render_submit(bufs[i % D].data_ptr(), W, H, camera=cam, max_depth=max_depth, aa=(AA, AA), flags=FLAGS))
     for t in pend:
         sc.render_wait(t)
     torch.cuda.synchronize(); piped = (time.perf_counter() - t0) / n

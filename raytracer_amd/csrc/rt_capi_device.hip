@@ -882,7 +882,11 @@ struct Run {
 				const bool fused = ((!packets && lv > 0) || smallLevel0) && !sc->texelFix && getenv("RT_NO_FUSED_LEVELS") == nullptr;
 				// ... and the exit searches of transmitted rays as well where they are analytic (no CSG object, no triangle transmits): such a
 				// level, like one of a scene without transmission, is a single launch that also reports its counts
-				const bool inlineX = fused && sc->hasTransmissive && sc->transmitAnalytic && getenv("RT_NO_INLINE_TRANSMIT") == nullptr;
+				// Where they are not (CSG objects, meshes) they still go inline on levels small enough to be latency-bound -- a launch of a few
+				// hundred waves lasts as long as its slowest lane either way, and a k_transmit behind it adds its own slowest exit search on top
+				// (C3's deepest levels, scene l) -- while on large levels a few trapped rays would hold waves that have work waiting behind them.
+				static const uint32_t inlineMax = envU32("RT_INLINE_TRANSMIT_MAX", 1048576);
+				const bool inlineX = fused && sc->hasTransmissive && (sc->transmitAnalytic || nb <= inlineMax) && getenv("RT_NO_INLINE_TRANSMIT") == nullptr;
 				const bool selfReport = fused && (!sc->hasTransmissive || inlineX) && getenv("RT_NO_SELF_REPORT") == nullptr;
 				seqOf[lv] = ++ln->reportSeq ? ln->reportSeq : ++ln->reportSeq;   // (never 0)
 				if (fused) rtk_level(st, sc->dev, sc->small, sc->hasCsg, inlineX, ln->ray[cur], nb, nDev, ln->ray[cur ^ 1], ln->surfq, ln->transq, &L[lv], acc, aaSq, maxDepth,

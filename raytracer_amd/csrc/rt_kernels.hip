@@ -1574,7 +1574,7 @@ template <bool CSG, bool SMALL, bool XINLINE>
 __global__ __launch_bounds__(kBlock) void k_level(DevScene Sg, RtSmallScene small, RtQueue rq, uint32_t nArg, const uint32_t* nDev, RtQueue nq, RtQueue sq, RtQueue tq, RtCounters* ctr,
                                                   RtAccum A, uint32_t aaSq, int maxDepth, int surfaces, const int32_t* lightList, uint32_t nLights,
                                                   uint32_t* stateCases, RtLevelReport* report, uint32_t seq) {
-	static_assert(!(CSG && XINLINE), "exit searches on CSG objects stay in k_transmit");
+	// (CSG && XINLINE: every kind of object, CSG evaluations and mesh walks included -- chosen where the levels are latency-bound, see rtk_level)
 	extern __shared__ uint4 levelLds[];
 	__shared__ int32_t stackStatic[SMALL ? 1 : kStack][kBlock];
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -1627,7 +1627,7 @@ __global__ __launch_bounds__(kBlock) void k_level(DevScene Sg, RtSmallScene smal
 		f3 outPoint, outVector;
 		uint32_t failedSearches = 0;
 		CsgScratch store;
-		const bool ok = transmitRay<false, false, CsgScratch, false>(S, prim, o.refraction, o.p, d, o.N, outPoint, outVector, store, RtPick{ nullptr, nullptr, 0 }, path, failedSearches);
+		const bool ok = transmitRay<CSG, false, CsgScratch>(S, prim, o.refraction, o.p, d, o.N, outPoint, outVector, store, RtPick{ nullptr, nullptr, 0 }, path, failedSearches);
 		if (failedSearches != 0u) { const uint32_t was = atomicAdd(stateCases, failedSearches); asm volatile("" :: "v"(was)); }   // (returned: complete before the workgroup's ticket)
 		wantT = false;
 		if (ok) {
@@ -2428,12 +2428,14 @@ void rtk_level(hipStream_t st, const DevScene& S, const RtSmallScene& small, boo
 #define RT_LEVEL_ARGS S, small, rq, n, nDev, nq, sq, tq, ctr, A, aaSq, maxDepth, surfaces, lightList, nLights, stateCases, report, seq
 	if (small.blob && getenv("RT_NO_SMALL_SCENE") == nullptr) {   // (the switch: read per call, for the tests)
 		const size_t lds = (size_t)small.stackRows * kBlock * 4u + small.bytes;
-		if (csg) RT_LAUNCH_S((k_level<true, true, false>), n, lds, st, RT_LEVEL_ARGS);
+		if (csg && inlineTransmit) RT_LAUNCH_S((k_level<true, true, true>), n, lds, st, RT_LEVEL_ARGS);
+		else if (csg) RT_LAUNCH_S((k_level<true, true, false>), n, lds, st, RT_LEVEL_ARGS);
 		else if (inlineTransmit) RT_LAUNCH_S((k_level<false, true, true>), n, lds, st, RT_LEVEL_ARGS);
 		else RT_LAUNCH_S((k_level<false, true, false>), n, lds, st, RT_LEVEL_ARGS);
 		return;
 	}
-	if (csg) RT_LAUNCH((k_level<true, false, false>), n, st, RT_LEVEL_ARGS);
+	if (csg && inlineTransmit) RT_LAUNCH((k_level<true, false, true>), n, st, RT_LEVEL_ARGS);
+	else if (csg) RT_LAUNCH((k_level<true, false, false>), n, st, RT_LEVEL_ARGS);
 	else if (inlineTransmit) RT_LAUNCH((k_level<false, false, true>), n, st, RT_LEVEL_ARGS);
 	else RT_LAUNCH((k_level<false, false, false>), n, st, RT_LEVEL_ARGS);
 #undef RT_LEVEL_ARGS

@@ -16,6 +16,7 @@
 #include "bmp_io.h"
 #include "json_min.h"
 #include "host_internal.h"
+#include "std_sort_par.h"
 
 #include <algorithm>
 #include <chrono>
@@ -28,6 +29,7 @@
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 using rt::vec3;
@@ -66,6 +68,18 @@ void put3(float* dst, vec3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
 
 struct Box6 { float b[6]; };   // minX,maxX,minY,maxY,minZ,maxZ
 
+// f(begin, end, chunk) over [0, n) in up to kMaxChunks chunks of at least minChunk items, each on a thread of its own (the caller's included)
+constexpr size_t kMaxChunks = 16;
+template <class F> void parallelChunks(size_t n, size_t minChunk, F f) {
+	const size_t hw = std::max<size_t>(1, std::min<size_t>(kMaxChunks, std::thread::hardware_concurrency()));
+	const size_t chunks = std::min(hw, n / std::max<size_t>(minChunk, 1));
+	if (chunks <= 1) { f((size_t)0, n, (size_t)0); return; }
+	std::vector<std::future<void>> rest;
+	for (size_t c = 1; c < chunks; c++) rest.push_back(std::async(std::launch::async, [=, &f] { f(n * c / chunks, n * (c + 1) / chunks, c); }));
+	f((size_t)0, n / chunks, (size_t)0);
+	for (auto& r : rest) r.get();
+}
+
 // An object as the BVH constructor sees it (bvh.cpp:10-28): its box, its centroid, and where it lives.
 struct BuildObj {
 	uint32_t type;      // RT_PRIM_*
@@ -82,7 +96,7 @@ struct BuildObj {
 struct MeshData {
 	const Value* tj = nullptr;
 	const Value* uvj = nullptr;
-	std::vector<float> pos, uv;
+	rt::PodVec<float> pos, uv;   // (read straight from the file: no zero-fill first)
 	size_t count = 0;
 	bool hasUv = false;
 
@@ -121,10 +135,10 @@ struct Loader {
 	std::string assetDir;
 	// scene-order staging (the BVH flatten re-emits these in leaf order)
 	std::vector<rt_sphere> spheres;
-	std::vector<rt_tri> tris;
+	rt::PodVec<rt_tri> tris;
 	std::vector<rt_box> boxes;
 	std::vector<rt_csg> csgs;
-	std::vector<BuildObj> bvhObjs;
+	rt::PodVec<BuildObj> bvhObjs;
 	int32_t nextBvhId = 0;
 
 	int addTexture(const std::string& file) {
@@ -164,7 +178,7 @@ struct Loader {
 		b.b[0] = c.x - r; b.b[1] = c.x + r; b.b[2] = c.y - r; b.b[3] = c.y + r; b.b[4] = c.z - r; b.b[5] = c.z + r;
 		return b;
 	}
-	static Box6 meshBox(const std::vector<rt_tri>& ts, size_t first, size_t count) {   // Mesh::setBox, objects.cpp:315-325
+	static Box6 meshBox(const rt::PodVec<rt_tri>& ts, size_t first, size_t count) {   // Mesh::setBox, objects.cpp:315-325
 		Box6 b = triBox(ts[first]);
 		for (size_t i = 1; i < count; i++) {
 			Box6 c = triBox(ts[first + i]);
@@ -227,77 +241,141 @@ struct Loader {
 	}
 
 	// ---- BVH (bvh.cpp:37-70,162-214) ----
-	static Box6 unionBox(const std::vector<BuildObj>& all, const std::vector<int>& objs) {   // BVH_node::BVH_node
-		Box6 b = all[objs[0]].box;
-		for (size_t i = 1; i < objs.size(); i++) {
-			const Box6& c = all[objs[i]].box;
-			b.b[0] = std::min(b.b[0], c.b[0]); b.b[1] = std::max(b.b[1], c.b[1]);
-			b.b[2] = std::min(b.b[2], c.b[2]); b.b[3] = std::max(b.b[3], c.b[3]);
-			b.b[4] = std::min(b.b[4], c.b[4]); b.b[5] = std::max(b.b[5], c.b[5]);
+	static void growBox(Box6& b, const Box6& c) {
+		b.b[0] = std::min(b.b[0], c.b[0]); b.b[1] = std::max(b.b[1], c.b[1]);
+		b.b[2] = std::min(b.b[2], c.b[2]); b.b[3] = std::max(b.b[3], c.b[3]);
+		b.b[4] = std::min(b.b[4], c.b[4]); b.b[5] = std::max(b.b[5], c.b[5]);
+	}
+	// (min and max are exact and associative: the chunks of a long list may be reduced on separate threads)
+	static Box6 unionBox(const rt::PodVec<Box6>& all, const int* objs, size_t n) {   // BVH_node::BVH_node
+		if (n < 200000) {
+			Box6 b = all[(size_t)objs[0]];
+			for (size_t i = 1; i < n; i++) growBox(b, all[(size_t)objs[i]]);
+			return b;
 		}
+		std::vector<Box6> part(kMaxChunks, all[(size_t)objs[0]]);
+		parallelChunks(n, 50000, [&](size_t begin, size_t end, size_t chunk) {
+			Box6 b = all[(size_t)objs[begin]];
+			for (size_t i = begin + 1; i < end; i++) growBox(b, all[(size_t)objs[i]]);
+			part[chunk] = b;
+		});
+		Box6 b = part[0];
+		for (const Box6& c : part) growBox(b, c);
 		return b;
 	}
 
 	// The reference's build (bvh.cpp:37-70) in two steps: the splits -- each node sorts its own object list, so sibling
 	// subtrees are independent and the top levels are built on separate threads (the sorts are where the time of a
 	// 5 M-triangle scene goes; every sort sees exactly the list it sees in the reference, so the tree is the same) --
-	// and then the flattening into pre-order nodes and leaf-order primitives, which is sequential.
+	// and then the flattening into pre-order nodes and leaf-order primitives, every subtree into ranges known from the counts.
 	struct TreeNode {
 		Box6 lb, rb;
 		std::unique_ptr<TreeNode> l, r;
-		std::vector<int> objs;   // leaf contents (leaf iff l == nullptr)
+		size_t first = 0, count = 0;   // leaf contents (leaf iff l == nullptr): order[first, first + count)
+		// what the subtree adds to the flat arrays: inner nodes, and primitives of each type (spheres, triangles, boxes, CSG objects)
+		int64_t nNodes = 0, nOfType[4] = { 0, 0, 0, 0 };
+		int64_t prims() const { return nOfType[0] + nOfType[1] + nOfType[2] + nOfType[3]; }
 	};
-	std::unique_ptr<TreeNode> splitNode(std::vector<int>& objs, const Box6& box, int depth) const {
+	// A node's object list is a range of `order` (indices into bvhObjs): sorting the range and halving it leaves the two children's
+	// lists where they are, in the order the reference's copies would have (bvh.cpp:58-66), and no list is ever allocated.  `keyed` is
+	// the scratch the sorts run in: the range's centroids along the split axis gathered beside the indices.
+	struct KeyIdx { float key; int idx; };
+	rt::PodVec<int> order;
+	rt::PodVec<KeyIdx> keyed;
+	rt::PodVec<float> centroidOf[3];   // the objects' centroids, one array per axis, and their boxes: what the splits read, 4 and 24 B per object
+	rt::PodVec<Box6> boxOf;
+	std::unique_ptr<TreeNode> splitNode(size_t first, size_t n, const Box6& box, int depth) {
 		std::unique_ptr<TreeNode> t(new TreeNode());
-		if (objs.size() <= 2 || depth >= RT_MAX_BVH_DEPTH) {   // bvh.cpp:39
-			t->objs.swap(objs);
+		if (n <= 2 || depth >= RT_MAX_BVH_DEPTH) {   // bvh.cpp:39
+			t->first = first; t->count = n;
+			for (size_t i = 0; i < n; i++) t->nOfType[bvhObjs[(size_t)order[first + i]].type]++;
 			return t;
 		}
 		float lengthX = box.b[1] - box.b[0], lengthY = box.b[3] - box.b[2], lengthZ = box.b[5] - box.b[4];
 		int axis = (lengthX >= lengthY && lengthX >= lengthZ) ? 0 : (lengthY >= lengthZ ? 1 : 2);   // bvh.cpp:48-56
-		const std::vector<BuildObj>& all = bvhObjs;
-		std::sort(objs.begin(), objs.end(), [&all, axis](int a, int b) { return all[a].centroid[axis] < all[b].centroid[axis]; });
-		std::vector<int> left(objs.begin(), objs.begin() + objs.size() / 2);
-		std::vector<int> right(objs.begin() + objs.size() / 2, objs.end());
-		std::vector<int>().swap(objs);   // the reference keeps the parent's list alive; we do not need it
-		t->lb = unionBox(all, left); t->rb = unionBox(all, right);
-		if (depth < 4 && left.size() + right.size() > 20000) {
-			auto fut = std::async(std::launch::async, [&] { return splitNode(left, t->lb, depth + 1); });
-			t->r = splitNode(right, t->rb, depth + 1);
+		const float* cen = centroidOf[axis].data();
+		// sortObjects (bvh.cpp:188-213): std::sort of the list by centroid.  With the keys beside the indices the comparisons, and with them
+		// the permutation, stay the ones of std::sort(objs, [](a, b) { return centroid(a) < centroid(b); }) without two random reads per
+		// comparison; a long list is sorted by std_sort_par.h, which is std::sort on several threads.
+		int* objs = order.data() + first;
+		KeyIdx* keys = keyed.data() + first;
+		bool ordered = true;   // (a NaN centroid is no strict weak ordering: whatever std::sort does with it, it does here)
+		if (n >= 200000) {
+			std::vector<char> bad(kMaxChunks, 0);
+			parallelChunks(n, 50000, [&](size_t begin, size_t end, size_t chunk) {
+				for (size_t i = begin; i < end; i++) { keys[i] = { cen[(size_t)objs[i]], objs[i] }; if (keys[i].key != keys[i].key) bad[chunk] = 1; }
+			});
+			for (char c : bad) if (c) ordered = false;
+		} else for (size_t i = 0; i < n; i++) { keys[i] = { cen[(size_t)objs[i]], objs[i] }; if (keys[i].key != keys[i].key) ordered = false; }
+		auto less = [](const KeyIdx& x, const KeyIdx& y) { return x.key < y.key; };
+		static const bool plainSort = getenv("RT_LOADER_STD_SORT") != nullptr;   // (the switch: for the tests)
+		if (n >= 100000 && ordered && !plainSort) rt::stdSortParallel(keys, (long)n, less, (long)std::max<size_t>(1 << 15, n / 64));
+		else std::sort(keys, keys + n, less);
+		for (size_t i = 0; i < n; i++) objs[i] = keys[i].idx;
+		const size_t nl = n / 2, nr = n - n / 2;   // bvh.cpp:58-66
+		t->lb = unionBox(boxOf, objs, nl); t->rb = unionBox(boxOf, objs + nl, nr);
+		if (depth < 6 && n > 20000) {   // (64 subtrees at most: enough to keep 16 cores busy to the end)
+			auto fut = std::async(std::launch::async, [&] { return splitNode(first, nl, t->lb, depth + 1); });
+			t->r = splitNode(first + nl, nr, t->rb, depth + 1);
 			t->l = fut.get();
 		} else {
-			t->l = splitNode(left, t->lb, depth + 1);
-			t->r = splitNode(right, t->rb, depth + 1);
+			t->l = splitNode(first, nl, t->lb, depth + 1);
+			t->r = splitNode(first + nl, nr, t->rb, depth + 1);
 		}
+		t->nNodes = 1 + t->l->nNodes + t->r->nNodes;
+		for (int k = 0; k < 4; k++) t->nOfType[k] = t->l->nOfType[k] + t->r->nOfType[k];
 		return t;
 	}
+	// Where a subtree's output starts in the flat arrays: its inner nodes in bvh_nodes (pre-order), its primitives in leaf_prims (leaf
+	// order) and in the arrays of their types.  The counts of every subtree are known from the split (TreeNode::nNodes / nOfType), so the
+	// subtrees of the top levels are written on separate threads, each into its own ranges -- the arrays come out as a sequential
+	// pre-order walk would fill them.
+	struct FlatAt { int64_t node, prim, ofType[4]; };
 	// Returns the (child, count) reference of the subtree `t`.
-	void flattenNode(const TreeNode& t, int32_t& childOut, int32_t& countOut) {
+	void flattenNode(const TreeNode& t, FlatAt at, int depth, int32_t& childOut, int32_t& countOut) {
 		if (!t.l) {
-			childOut = ~(int32_t)S->leaf_prims.size();
-			countOut = (int32_t)t.objs.size();
-			for (int oi : t.objs) emitLeafPrim(bvhObjs[oi]);
-			S->leaf_prims.back() |= RT_PRIM_LAST;   // device leaf loops run until this flag instead of carrying a count
+			childOut = ~(int32_t)at.prim;
+			countOut = (int32_t)t.count;
+			for (size_t i = 0; i < t.count; i++) {
+				const BuildObj& o = bvhObjs[(size_t)order[t.first + i]];
+				const int64_t k = at.ofType[o.type]++;
+				S->leaf_prims[(size_t)at.prim++] = RT_PRIM_REF(o.type, k);
+				switch (o.type) {
+				case RT_PRIM_SPHERE: S->spheres[(size_t)k] = spheres[(size_t)o.src]; break;
+				case RT_PRIM_TRI: S->tris[(size_t)k] = tris[(size_t)o.src]; break;
+				case RT_PRIM_BOX: S->boxes[(size_t)k] = boxes[(size_t)o.src]; break;
+				case RT_PRIM_CSG: S->csgs[(size_t)k] = csgs[(size_t)o.src]; break;
+				}
+			}
+			S->leaf_prims[(size_t)at.prim - 1] |= RT_PRIM_LAST;   // device leaf loops run until this flag instead of carrying a count
 			return;
 		}
-		int32_t self = (int32_t)S->bvh_nodes.size();
-		S->bvh_nodes.push_back(rt_bvh_node());
+		const int64_t self = at.node;
+		FlatAt left = at, right = at;
+		left.node = self + 1;
+		right.node = self + 1 + t.l->nNodes;
+		right.prim = at.prim + t.l->prims();
+		for (int k = 0; k < 4; k++) right.ofType[k] = at.ofType[k] + t.l->nOfType[k];
 		int32_t c0, n0, c1, n1;
-		flattenNode(*t.l, c0, n0);
-		flattenNode(*t.r, c1, n1);
-		rt_bvh_node& n = S->bvh_nodes[self];
+		if (depth < 4 && t.prims() > 20000) {
+			auto fut = std::async(std::launch::async, [&] { flattenNode(*t.l, left, depth + 1, c0, n0); });
+			flattenNode(*t.r, right, depth + 1, c1, n1);
+			fut.get();
+		} else {
+			flattenNode(*t.l, left, depth + 1, c0, n0);
+			flattenNode(*t.r, right, depth + 1, c1, n1);
+		}
+		rt_bvh_node& n = S->bvh_nodes[(size_t)self];
 		memcpy(n.box[0], t.lb.b, sizeof t.lb.b); memcpy(n.box[1], t.rb.b, sizeof t.rb.b);
 		n.child[0] = c0; n.child[1] = c1; n.count[0] = n0; n.count[1] = n1;
-		childOut = self; countOut = 0;
+		childOut = (int32_t)self; countOut = 0;
 	}
-
-	void emitLeafPrim(const BuildObj& o) {
-		switch (o.type) {
-		case RT_PRIM_SPHERE: S->leaf_prims.push_back(RT_PRIM_REF(RT_PRIM_SPHERE, S->spheres.size())); S->spheres.push_back(spheres[o.src]); break;
-		case RT_PRIM_TRI: S->leaf_prims.push_back(RT_PRIM_REF(RT_PRIM_TRI, S->tris.size())); S->tris.push_back(tris[o.src]); break;
-		case RT_PRIM_BOX: S->leaf_prims.push_back(RT_PRIM_REF(RT_PRIM_BOX, S->boxes.size())); S->boxes.push_back(boxes[o.src]); break;
-		case RT_PRIM_CSG: S->leaf_prims.push_back(RT_PRIM_REF(RT_PRIM_CSG, S->csgs.size())); S->csgs.push_back(csgs[o.src]); break;
-		}
+	void flattenTree(const TreeNode& root, int32_t& childOut, int32_t& countOut) {
+		S->bvh_nodes.assign((size_t)root.nNodes, rt_bvh_node());
+		S->leaf_prims.assign((size_t)root.prims(), 0u);
+		S->spheres.resize((size_t)root.nOfType[RT_PRIM_SPHERE]); S->tris.resize((size_t)root.nOfType[RT_PRIM_TRI]);
+		S->boxes.resize((size_t)root.nOfType[RT_PRIM_BOX]); S->csgs.resize((size_t)root.nOfType[RT_PRIM_CSG]);
+		flattenNode(root, FlatAt{ 0, 0, { 0, 0, 0, 0 } }, 0, childOut, countOut);
 	}
 
 	static rt_material parseMaterial(const Value& mj) {   // raytracer.cpp:149-165
@@ -354,28 +432,40 @@ struct Loader {
 				p.id = planeId++; p.mat = mat;
 				S->planes.push_back(p);
 			} else if (type.is("mesh") || type.is("texturemesh")) {
+				const bool timing = getenv("RT_LOAD_TIMING") != nullptr;
+				auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+				const double m0 = now();
 				MeshData md;
 				md.load(object, assetDir);
+				const double m1 = now();
 				bool textured = type.is("texturemesh");
 				rt_mesh m;
 				m.tri_first = (int32_t)S->mesh_tris.size(); m.tri_count = (int32_t)md.count; m.tex = -1; m.mat = mat;
 				int meshIdx = (int)S->meshes.size();
 				if (textured) m.tex = addTexture(object["texture"].string());
-				tris.reserve(tris.size() + md.count); S->mesh_tris.reserve(S->mesh_tris.size() + md.count); bvhObjs.reserve(bvhObjs.size() + md.count);
-				for (size_t i = 0; i < md.count; i++) {
-					rt_tri t = makeTri(md.vertex(i, 0), md.vertex(i, 1), md.vertex(i, 2), mat, meshIdx);
-					t.id = nextBvhId++;
-					if (textured) {   // raytracer.cpp:210-220
-						rt_uv uv;
-						md.uvOf(i, uv.uv);
-						t.uv = (int32_t)S->uvs.size();
-						S->uvs.push_back(uv);
+				// (every triangle's records land at known places: the triangles of a large mesh are made on several threads)
+				const size_t triBase = tris.size(), meshTriBase = S->mesh_tris.size(), objBase = bvhObjs.size(), uvBase = S->uvs.size();
+				const int32_t idBase = nextBvhId;
+				tris.resize(triBase + md.count); S->mesh_tris.resize(meshTriBase + md.count); bvhObjs.resize(objBase + md.count);
+				if (textured) S->uvs.resize(uvBase + md.count);
+				parallelChunks(md.count, 100000, [&](size_t begin, size_t end, size_t) {
+					for (size_t i = begin; i < end; i++) {
+						rt_tri t = makeTri(md.vertex(i, 0), md.vertex(i, 1), md.vertex(i, 2), mat, meshIdx);
+						t.id = idBase + (int32_t)i;
+						if (textured) {   // raytracer.cpp:210-220
+							rt_uv uv;
+							md.uvOf(i, uv.uv);
+							t.uv = (int32_t)(uvBase + i);
+							S->uvs[uvBase + i] = uv;
+						}
+						BuildObj b; b.type = RT_PRIM_TRI; b.src = (int)(triBase + i); b.box = triBox(t);
+						b.centroid = vec3((t.p0[0] + t.p1[0] + t.p2[0]) / 3, (t.p0[1] + t.p1[1] + t.p2[1]) / 3, (t.p0[2] + t.p1[2] + t.p2[2]) / 3);   // objects.cpp:267-271
+						tris[triBase + i] = t; S->mesh_tris[meshTriBase + i] = t; bvhObjs[objBase + i] = b;
 					}
-					BuildObj b; b.type = RT_PRIM_TRI; b.src = (int)tris.size(); b.box = triBox(t);
-					b.centroid = vec3((t.p0[0] + t.p1[0] + t.p2[0]) / 3, (t.p0[1] + t.p1[1] + t.p2[1]) / 3, (t.p0[2] + t.p1[2] + t.p2[2]) / 3);   // objects.cpp:267-271
-					tris.push_back(t); S->mesh_tris.push_back(t); bvhObjs.push_back(b);
-				}
+				});
+				nextBvhId += (int32_t)md.count;
 				S->meshes.push_back(m);
+				if (timing && md.count > 100000) fprintf(stderr, "[load] mesh of %zu triangles: read %.2f s, triangles %.2f s\n", md.count, m1 - m0, now() - m1);
 			} else if (type.is("csgobject")) {
 				rt_csg c;
 				memset(&c, 0, sizeof c);
@@ -443,15 +533,24 @@ struct Loader {
 		V.root_child = -1; V.root_count = 0;
 		memset(V.root_box, 0, sizeof V.root_box);
 		if (!bvhObjs.empty()) {
-			std::vector<int> all(bvhObjs.size());
-			for (size_t i = 0; i < all.size(); i++) all[i] = (int)i;
-			Box6 rootBox = unionBox(bvhObjs, all);
+			order.resize(bvhObjs.size());
+			parallelChunks(order.size(), 100000, [&](size_t begin, size_t end, size_t) { for (size_t i = begin; i < end; i++) order[i] = (int)i; });
+			keyed.resize(order.size());
+			boxOf.resize(order.size());
+			for (int a = 0; a < 3; a++) centroidOf[a].resize(order.size());
+			parallelChunks(order.size(), 100000, [&](size_t begin, size_t end, size_t) {
+				for (size_t i = begin; i < end; i++) {
+					const BuildObj& o = bvhObjs[i];
+					boxOf[i] = o.box; centroidOf[0][i] = o.centroid.x; centroidOf[1][i] = o.centroid.y; centroidOf[2][i] = o.centroid.z;
+				}
+			});
+			Box6 rootBox = unionBox(boxOf, order.data(), order.size());
 			memcpy(V.root_box, rootBox.b, sizeof rootBox.b);
 			const bool timing = getenv("RT_LOAD_TIMING") != nullptr;
 			const auto t0 = std::chrono::steady_clock::now();
-			std::unique_ptr<TreeNode> tree = splitNode(all, rootBox, 0);
+			std::unique_ptr<TreeNode> tree = splitNode(0, order.size(), rootBox, 0);
 			const auto t1 = std::chrono::steady_clock::now();
-			flattenNode(*tree, V.root_child, V.root_count);
+			flattenTree(*tree, V.root_child, V.root_count);
 			const auto t2 = std::chrono::steady_clock::now();
 			if (timing) fprintf(stderr, "[load] bvh split %.2f s, flatten %.2f s\n", std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count());
 		}
@@ -464,12 +563,21 @@ int loadFromText(const std::string& text, const char* assetDir, rt_flat_scene** 
 	*out = nullptr;
 	auto* store = new rt::FlatSceneStore();
 	try {
+		const bool timing = getenv("RT_LOAD_TIMING") != nullptr;
+		auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		const double t0 = now();
 		Value scene = rtjson::Parser::parse(text);
-		Loader L;
-		L.S = store;
-		L.assetDir = assetDir ? assetDir : "";
-		if (!L.assetDir.empty() && L.assetDir.back() != '/') L.assetDir += '/';
-		L.load(scene);
+		const double t1 = now();
+		double t2;
+		{
+			Loader L;
+			L.S = store;
+			L.assetDir = assetDir ? assetDir : "";
+			if (!L.assetDir.empty() && L.assetDir.back() != '/') L.assetDir += '/';
+			L.load(scene);
+			t2 = now();
+		}
+		if (timing) fprintf(stderr, "[load] json %.2f s, objects + tree %.2f s, staging freed %.2f s\n", t1 - t0, t2 - t1, now() - t2);
 	} catch (const std::exception& e) {
 		delete store;
 		rt::set_error(std::string("scene: ") + e.what());
@@ -519,7 +627,8 @@ template <class T> static bool wr(FILE* f, const T* p, int64_t count) {
 }
 // One array of the file.  The count is not trusted: it must fit what is left of the file (a corrupt count must not turn
 // into a 64 GB resize) and, except for the texel bytes, the int32 counts of rt_flat_scene.
-template <class T> static bool rd(FILE* f, std::vector<T>& v, uint64_t& left, bool wide = false) {
+template <class V> static bool rd(FILE* f, V& v, uint64_t& left, bool wide = false) {
+	using T = typename V::value_type;
 	uint64_t n = 0;
 	if (left < 8 || fread(&n, 8, 1, f) != 1) return false;
 	left -= 8;

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <future>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -1144,6 +1145,8 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	auto fail = [&](int rc) { rt_scene_free(sc); return rc; };
 	DevScene& D = sc->dev;
 	int rc;
+	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double tArr0 = now();
 	if ((rc = sc->upload(s->planes, s->n_planes, &D.planes))) return fail(rc);
 	if ((rc = sc->upload(s->spheres, s->n_spheres, &D.spheres))) return fail(rc);
 	if ((rc = sc->upload(s->tris, s->n_tris, &D.tris))) return fail(rc);
@@ -1160,7 +1163,6 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	if ((rc = sc->upload(s->leaf_prims, s->n_leaf_prims, &D.leaf_prims))) return fail(rc);
 	const bool timing = getenv("RT_LOAD_TIMING") != nullptr;
 	size_t treeletBytes = 0; int treeDepth = 0;
-	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double tUp0 = now();
 	{
 		MeshTrees mt;
@@ -1171,42 +1173,51 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	}
 	{
 		static_assert(sizeof(rt_tri) == sizeof(rt_bvh_node) && sizeof(rt_bvh_node) == 64, "treelet slots are 64 B");
-		std::vector<rt_bvh_node> treelets;
-		bool externalRuns = false;
+		std::vector<rt_bvh_node> treelets, quads;
+		bool externalRuns = false, quadRuns = false;
+		int quadDepth = 0;
 		AugTree aug;
 		const double tA0 = now();
 		buildAugTree(s, getenv("RT_NO_SPLIT") == nullptr, aug);
 		const double tA1 = now();
 		if (aug.depth > RT_STACK_DEPTH) buildAugTree(s, false, aug);   // (a leaf of > 4 * 2^20 triangles)
-		int levels = buildTreelets(s, aug, getenv("RT_NO_EMBED") == nullptr, treelets, externalRuns);
-		if (levels > RT_TREELET_MAX_LEVELS) { buildAugTree(s, false, aug); levels = buildTreelets(s, aug, false, treelets, externalRuns); }
-		if (levels < 0) return fail(RT_EINVAL);
+		// The two forms of the tree -- binary treelets for the per-lane walks, quad treelets for the packet walks -- are cut from the same
+		// augmented tree independently of each other: the first on a thread of its own while this one cuts the second.
+		const bool embed = getenv("RT_NO_EMBED") == nullptr;
+		std::string treeletError;
+		auto binary = std::async(std::launch::async, [&] {
+			const int l = buildTreelets(s, aug, embed, treelets, externalRuns);
+			if (l < 0) treeletError = rt_last_error();   // (the error text is per thread)
+			return l;
+		});
+		int qlevels = buildQuadTreelets(s, aug, embed, quads, quadRuns, quadDepth);
+		int levels = binary.get();
+		if (levels < 0) { rt::set_error(treeletError); return fail(RT_EINVAL); }
+		if (levels > RT_TREELET_MAX_LEVELS) {   // too deep a cut: both forms again over the tree without sub-trees, nothing embedded
+			buildAugTree(s, false, aug);
+			levels = buildTreelets(s, aug, false, treelets, externalRuns);
+			if (levels >= 0) qlevels = buildQuadTreelets(s, aug, embed, quads, quadRuns, quadDepth);
+		}
+		if (qlevels > RT_TREELET_MAX_LEVELS) qlevels = buildQuadTreelets(s, aug, false, quads, quadRuns, quadDepth);
+		if (levels < 0 || qlevels < 0) return fail(RT_EINVAL);
 		if (levels > RT_TREELET_MAX_LEVELS || treelets.size() / RT_TREELET_SLOTS >= RT_TREELET_CONS / RT_TREELET_SLOTS) { rt::set_error("BVH too deep or too large for the treelet layout"); return fail(RT_ELIMIT); }
-		if (timing) fprintf(stderr, "[upload] arrays + mesh trees %.2f s, sub-trees %.2f s, treelets %.2f s: %zu treelets, %d levels, tree depth %d\n", tA0 - tUp0, tA1 - tA0, now() - tA1, treelets.size() / RT_TREELET_SLOTS, levels, aug.depth);
+		if (qlevels > RT_TREELET_MAX_LEVELS || quads.size() / RT_QUAD_SLOTS >= RT_TREELET_CONS / RT_QUAD_SLOTS || !RT_PACKET_STACK_FITS(quadDepth)) {
+			rt::set_error("BVH too deep or too large for the quad-node layout"); return fail(RT_ELIMIT);
+		}
+		const double tT0 = now();
+		if (timing) fprintf(stderr, "[upload] arrays %.2f s, mesh trees %.2f s, sub-trees %.2f s, treelets and quads %.2f s: %zu treelets, %d levels, tree depth %d; %zu quad treelets, %d levels, depth %d\n",
+		                    tUp0 - tArr0, tA0 - tUp0, tA1 - tA0, tT0 - tA1, treelets.size() / RT_TREELET_SLOTS, levels, aug.depth, quads.size() / RT_QUAD_SLOTS, qlevels, quadDepth);
 		D.treelet_levels = levels;
-		D.treelet_staging = externalRuns ? 1 : 0;
+		D.treelet_staging = (externalRuns || quadRuns) ? 1 : 0;
+		D.quad_levels = qlevels;
 		const rt_bvh_node* tl = nullptr;
 		if ((rc = sc->upload(treelets.data(), (int64_t)treelets.size(), &tl))) return fail(rc);
 		D.treelets = reinterpret_cast<const float4*>(tl);
 		treeletBytes = treelets.size() * sizeof(rt_bvh_node); treeDepth = aug.depth;
-		{	// the packet walks' form of the same tree
-			std::vector<rt_bvh_node> quads;
-			bool quadRuns = false;
-			int quadDepth = 0;
-			const bool embedQ = getenv("RT_NO_EMBED") == nullptr;
-			int qlevels = buildQuadTreelets(s, aug, embedQ, quads, quadRuns, quadDepth);
-			if (qlevels > RT_TREELET_MAX_LEVELS) qlevels = buildQuadTreelets(s, aug, false, quads, quadRuns, quadDepth);
-			if (qlevels < 0) return fail(RT_EINVAL);
-			if (qlevels > RT_TREELET_MAX_LEVELS || quads.size() / RT_QUAD_SLOTS >= RT_TREELET_CONS / RT_QUAD_SLOTS || !RT_PACKET_STACK_FITS(quadDepth)) {
-				rt::set_error("BVH too deep or too large for the quad-node layout"); return fail(RT_ELIMIT);
-			}
-			if (timing) fprintf(stderr, "[upload] quads: %zu treelets, %d levels, depth %d\n", quads.size() / RT_QUAD_SLOTS, qlevels, quadDepth);
-			D.quad_levels = qlevels;
-			if (quadRuns) D.treelet_staging = 1;
-			const rt_bvh_node* ql = nullptr;
-			if ((rc = sc->upload(quads.data(), (int64_t)quads.size(), &ql))) return fail(rc);
-			D.quads = reinterpret_cast<const float4*>(ql);
-		}
+		const rt_bvh_node* ql = nullptr;
+		if ((rc = sc->upload(quads.data(), (int64_t)quads.size(), &ql))) return fail(rc);
+		D.quads = reinterpret_cast<const float4*>(ql);
+		if (timing) fprintf(stderr, "[upload] treelets and quads to the device %.2f s\n", now() - tT0);
 		D.treelet_root = s->root_child < 0 ? s->root_child : 0;
 		D.treelet_root_aux = (s->root_child < 0 && s->root_count > 0) ? externalAux(leafRun(s, s->root_child), s->root_child) : RT_TREELET_NO_RUN;
 		if (D.treelet_root_aux != RT_TREELET_NO_RUN) D.treelet_staging = 1;

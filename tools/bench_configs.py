@@ -28,7 +28,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def gpu_time(rt, torch, flat, W, H, aa, max_depth, eye, rot_x, reps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     sc = rt.Scene(flat, 0)
+    upload_s = time.perf_counter() - t0                   # rt_scene_upload: sub-trees, treelets, quads, copies
     cam = rt.Camera(flat.fov, W, H, eye=eye, rot_x=rot_x)
     bufs = [torch.zeros(H, W, 3, device="cuda") for _ in range(3)]
     st = sc.render_into(bufs[0].data_ptr(), W, H, aa=aa, camera=cam, max_depth=max_depth)
@@ -56,7 +59,7 @@ def gpu_time(rt, torch, flat, W, H, aa, max_depth, eye, rot_x, reps):
     sharded = piped_ms(0, 3)                              # every frame cut into a shard per lane, three frames in flight (round 2's form)
     whole = piped_ms(rt.RT_FLAG_WHOLE_FRAME, 6)           # whole frames dealt to the lanes, six in flight
     sc.close()
-    return alone, min(sharded, whole), st, sharded, whole
+    return alone, min(sharded, whole), st, sharded, whole, upload_s
 
 
 def run_all(out_path, log=print):
@@ -91,15 +94,24 @@ def run_all(out_path, log=print):
                 "dominant_kernel": b["dominant_kernel"], "frac": ks[0]["frac_of_valu_issue"] if ks else None, "kernels": ks,
                 "counters_from": os.path.relpath(os.path.abspath(roof_path), ROOT), "source_sha": buildinfo.source_sha()}
 
-    def one(name, label, flat, W, H, aa=1, max_depth=16, eye=(0.0, 0.0, 0.0), rot_x=0.0, reps=5, cpu_scale=1, cpu_aa=None, cpu_threads_only=False):
-        alone, piped, st, sharded, whole = gpu_time(rt, torch, flat, W, H, (aa, aa), max_depth, eye, rot_x, reps)
+    def one(name, label, flat, W, H, aa=1, max_depth=16, eye=(0.0, 0.0, 0.0), rot_x=0.0, reps=5, cpu_scale=1, cpu_aa=None, cpu_threads_only=False, load_s=None):
+        alone, piped, st, sharded, whole, upload_s = gpu_time(rt, torch, flat, W, H, (aa, aa), max_depth, eye, rot_x, reps)
         rays = st["rays_nearest"] + st["rays_shadow"]
         # CPU sample: same scene, camera and depth limit; resolution divided by cpu_scale per axis (and cpu_aa samples per pixel)
         cw, ch, ca = W // cpu_scale, H // cpu_scale, (aa if cpu_aa is None else cpu_aa)
         ccam = rt.Camera(flat.fov, cw, ch, eye=eye, rot_x=rot_x)
+        # (a bundled scene's frame is ~10 ms on 16 threads: frames are repeated, after a first one that warms the thread pool up, until
+        # 0.3 s have gone by, and the rate is all their rays over all their time)
         t0 = time.perf_counter()
         _, nn, ns = oracle.render(flat, ccam, cw, ch, aa=ca, max_depth=max_depth, seed=1, threads=threads)
         dN = time.perf_counter() - t0
+        cpu_frames = 1
+        if dN < 0.3:
+            cpu_frames, t0 = 0, time.perf_counter()
+            while cpu_frames < 3 or time.perf_counter() - t0 < 0.3:
+                oracle.render(flat, ccam, cw, ch, aa=ca, max_depth=max_depth, seed=1, threads=threads)
+                cpu_frames += 1
+            dN = (time.perf_counter() - t0) / cpu_frames
         cpuN = (nn + ns) / dN / 1e6
         cpu1 = None
         if not cpu_threads_only:
@@ -115,17 +127,18 @@ def run_all(out_path, log=print):
             cpu1 = (n1 + s1r) / d1 / 1e6
         row = {"config": name, "workload": label, "width": W, "height": H, "samples_per_pixel": aa * aa, "max_depth": max_depth,
                "rays_per_frame": int(rays), "levels": int(st["levels"]), "batch_splits": int(st["batch_splits"]),
+               "load_s": None if load_s is None else round(load_s, 3), "upload_s": round(upload_s, 3),
                "gpu_ms_per_frame": round(piped * 1e3, 4), "gpu_single_frame_ms": round(alone * 1e3, 4),
                "gpu_ms_per_frame_sharded_3_in_flight": round(sharded * 1e3, 4), "gpu_ms_per_frame_whole_frames_6_in_flight": round(whole * 1e3, 4),
                "gpu_mrays_s": round(rays / piped / 1e6, 1), "gpu_single_frame_mrays_s": round(rays / alone / 1e6, 1),
                "cpu_mrays_s_1_thread": None if cpu1 is None else round(cpu1, 3), "cpu_mrays_s_all_threads": round(cpuN, 3), "cpu_threads": threads,
-               "cpu_sample": f"{cw}x{ch}, {ca * ca} sample(s)/pixel, same scene, camera and depth limit ({nn + ns} rays in {dN:.2f} s on {threads} threads)",
+               "cpu_sample": f"{cw}x{ch}, {ca * ca} sample(s)/pixel, same scene, camera and depth limit ({nn + ns} rays in {dN * 1e3:.1f} ms on {threads} threads, mean of {cpu_frames} frame(s))",
                "gpu_over_cpu_all_threads": round(rays / piped / 1e6 / cpuN, 1),
                "gpu_over_cpu_1_thread": None if cpu1 is None else round(rays / piped / 1e6 / cpu1, 1),
                "roofline": roofline_of(name)}
         rows.append(row)
         log(f"{name}: GPU {row['gpu_ms_per_frame']} ms/frame (shards {row['gpu_ms_per_frame_sharded_3_in_flight']}, whole frames {row['gpu_ms_per_frame_whole_frames_6_in_flight']}, {row['gpu_single_frame_ms']} alone), {rays / 1e6:.2f} Mrays, {row['gpu_mrays_s']} Mrays/s; "
-            f"CPU {row['cpu_mrays_s_1_thread']} / {row['cpu_mrays_s_all_threads']} Mrays/s (1 / {threads} threads); x{row['gpu_over_cpu_all_threads']}")
+            f"CPU {row['cpu_mrays_s_1_thread']} / {row['cpu_mrays_s_all_threads']} Mrays/s (1 / {threads} threads); x{row['gpu_over_cpu_all_threads']}; set-up: load {row['load_s']} s, upload {row['upload_s']} s")
 
     with tempfile.TemporaryDirectory() as tmp:
         if not only or "C1" in only:
@@ -137,19 +150,23 @@ def run_all(out_path, log=print):
                 flat = rt.FlatScene.load(dst)
                 one(f"C1-{ch_}", f"bundled scene {ch_}.json, 640x480, 1 sample/pixel", flat, 640, 480, reps=10, cpu_scale=4 if ch_ == "m" else 1)
         if not only or "C2" in only:
-            flat = rt.FlatScene.from_json(scenes.c2_scene(tmp, grid=224))
-            one("C2", "100 352-triangle textured height field + 2 bump spheres, 1920x1080", flat, 1920, 1080, eye=(0.0, 1.5, 1.0), rot_x=-0.3, reps=10, cpu_scale=4)
+            path = scenes.c2_scene(tmp, grid=224)
+            t0 = time.perf_counter(); flat = rt.FlatScene.from_json(path); load_s = time.perf_counter() - t0   # (scene file -> flat scene: parsing, the reference's tree)
+            one("C2", "100 352-triangle textured height field + 2 bump spheres, 1920x1080", flat, 1920, 1080, eye=(0.0, 1.5, 1.0), rot_x=-0.3, reps=10, cpu_scale=4, load_s=load_s)
         if not only or "C3" in only:
-            flat = rt.FlatScene.from_json(scenes.c3_scene(tmp))
+            path = scenes.c3_scene(tmp)
+            t0 = time.perf_counter(); flat = rt.FlatScene.from_json(path); load_s = time.perf_counter() - t0   # (scene file -> flat scene: parsing, the reference's tree)
             one("C3", "64 nested CSG objects (half reflective, a quarter refractive), 1920x1080, depth limit 5", flat, 1920, 1080, max_depth=5,
-                eye=(0.0, 1.0, 2.0), rot_x=-0.25, reps=5, cpu_scale=4)
+                eye=(0.0, 1.0, 2.0), rot_x=-0.25, reps=5, cpu_scale=4, load_s=load_s)
         if not only or "C4" in only:
-            flat = rt.FlatScene.from_json(scenes.c4_scene(tmp, 64))
-            one("C4", "two area lights x 64 shadow samples per hit, 1920x1080", flat, 1920, 1080, reps=3, cpu_scale=8)
+            path = scenes.c4_scene(tmp, 64)
+            t0 = time.perf_counter(); flat = rt.FlatScene.from_json(path); load_s = time.perf_counter() - t0   # (scene file -> flat scene: parsing, the reference's tree)
+            one("C4", "two area lights x 64 shadow samples per hit, 1920x1080", flat, 1920, 1080, reps=3, cpu_scale=8, load_s=load_s)
         if not only or "C5" in only:
-            flat = rt.FlatScene.from_json(scenes.c5_scene(tmp, c5_grid))
+            path = scenes.c5_scene(tmp, c5_grid)
+            t0 = time.perf_counter(); flat = rt.FlatScene.from_json(path); load_s = time.perf_counter() - t0   # (scene file -> flat scene: parsing, the reference's tree)
             one("C5", f"{flat.info.n_tris}-triangle height field, 3840x2160, 4x4 samples/pixel", flat, 3840, 2160, aa=4, eye=(0.0, 1.5, 1.0), rot_x=-0.3,
-                reps=1, cpu_scale=8, cpu_aa=1)
+                reps=1, cpu_scale=8, cpu_aa=1, load_s=load_s)
     doc = {"note": "GPU: one MI355X, frames in flight (rt_render_submit: the better of shards with 3 outstanding and whole frames, RT_FLAG_WHOLE_FRAME, with 6; both given) and one frame alone (rt_render); rays = findNearest + calcShadow calls. "
                    "CPU: oracle/restate.cpp (the reference's algorithm, one ray at a time) on this box's host cores.",
            "cpu_threads": threads, "configs": rows}

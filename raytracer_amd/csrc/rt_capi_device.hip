@@ -118,7 +118,8 @@ struct rt_scene {
 		RtTexRec* texRec = nullptr;      // texelFix only
 	};
 	RtTexFix texFix(const Lane& ln) const { return RtTexFix{ texelFix ? ln.texRec : nullptr, texHeads, texCap, &ln.ctr->texrec_count }; }
-	uint32_t qcap = 0;
+	uint32_t qcap = 0;               // entries per queue (rays, hits, surfaces, requests of one lane's batch)
+	uint32_t qcapMax = 0;            // ... and how far rt_render_submit may grow them for large frames
 	int maxBlocks = 2048;            // grid cap of the persistent kernels
 	bool transmitAnalytic = false;   // the scene has no CSG object and no triangle of it transmits: exit searches are one analytic test per internal reflection (k_level does them inline)
 	RtSmallScene small;              // the scene's walk / shading arrays as one blob for k_level's LDS copy (small scenes only)
@@ -177,12 +178,30 @@ struct rt_scene {
 		q.f = static_cast<float*>(p); q.cap = qcap;
 		return RT_OK;
 	}
-	int initLane(Lane& ln, bool ownStream) {
+	int allocLaneQueues(Lane& ln) {
 		if (int rc = allocQueue(ln.ray[0], RQ_COMPS)) return rc;
 		if (int rc = allocQueue(ln.ray[1], RQ_COMPS)) return rc;
 		if (int rc = allocQueue(ln.hitq, HQ_COMPS)) return rc;
 		if (int rc = allocQueue(ln.surfq, SQ_COMPS)) return rc;
 		if (hasTransmissive) { if (int rc = allocQueue(ln.transq, TQ_COMPS)) return rc; }
+		return RT_OK;
+	}
+	// Larger queues for every lane (a frame whose share per lane does not fit the present ones in a batch or two: see rt_render_submit).
+	// The lanes must be idle and the GPU through with their work (drainLocked): the old buffers are released here.
+	int growQueues(uint32_t cap) {
+		for (Lane& ln : lanes)
+			for (RtQueue* q : { &ln.ray[0], &ln.ray[1], &ln.hitq, &ln.surfq, &ln.transq })
+				if (q->f) {
+					allocs.erase(std::remove(allocs.begin(), allocs.end(), (void*)q->f), allocs.end());
+					HIPCHK(hipFree(q->f));
+					*q = RtQueue{};
+				}
+		qcap = cap;
+		for (Lane& ln : lanes) if (int rc = allocLaneQueues(ln)) return rc;
+		return RT_OK;
+	}
+	int initLane(Lane& ln, bool ownStream) {
+		if (int rc = allocLaneQueues(ln)) return rc;
 		void* p = nullptr;
 		if (texelFix) {
 			HIPCHK(hipMalloc(&p, (size_t)texCap * sizeof(RtTexRec)));
@@ -1290,7 +1309,11 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 		}
 	}
 
+	// Queue entries per lane: 8 Mi to begin with (1.5 GB a lane), grown on demand up to 32 Mi when a frame brings more rays per lane than
+	// two batches hold (C5, 4K at 16 samples per pixel: 33 M primary rays a lane; 8 batches of 4 M leave every kernel's tail exposed eight
+	// times: 41.4 ms a frame against 38.8 with 32 Mi entries, and 39.6 with 64 Mi -- the lanes then overlap less).  RT_QUEUE_RAYS fixes the size.
 	sc->qcap = std::max<uint32_t>(1024, envU32("RT_QUEUE_RAYS", 8u << 20));
+	sc->qcapMax = getenv("RT_QUEUE_RAYS") ? sc->qcap : std::max(sc->qcap, envU32("RT_QUEUE_RAYS_MAX", 32u << 20));
 	sc->texCap = std::min<uint32_t>(sc->qcap, 2u << 20);
 	const int nLanes = (int)std::min<uint32_t>(RT_MAX_LANES, std::max<uint32_t>(1, envU32("RT_LANES", 4)));   // the box exposes 4 hardware queues per process
 	sc->lanes.resize(nLanes);
@@ -1376,6 +1399,16 @@ int rt_render_submit(rt_scene* sc, const rt_camera* camera, int width, int heigh
 		if (j.id && j.remaining > 0 && ((j.flags & (RT_FLAG_COUNTERS | RT_FLAG_TIME_KERNELS)) ||
 		    (!whole && !j.whole && (j.W != width || j.H != height || j.tileRank != tile_rank || j.tileRanks != tile_ranks || j.nShards != nShards))))
 			compatible = false;
+	// queues for this frame's share per lane: a batch is half a queue (its rays' children must fit beside them)
+	{
+		const uint64_t share = ((uint64_t)tiles * 256u /* 32 x 8 pixels */ * (uint64_t)(aa_x * aa_y) + (uint64_t)nShards - 1) / (uint64_t)nShards;
+		uint32_t want = sc->qcap;
+		while (want < sc->qcapMax && (uint64_t)want < 2 * share) want = (uint32_t)std::min<uint64_t>(2ull * want, sc->qcapMax);
+		if (want > sc->qcap) {
+			sc->drainLocked(g);
+			if (int rc = sc->growQueues(want)) return rc;
+		}
+	}
 	if (!compatible) sc->drainLocked(g);
 	if (int rc = whole ? sc->ensureLaneAccum(lane, (uint32_t)(width * height)) : sc->ensureAccum((uint32_t)(width * height))) return rc;
 	job->cam = *camera; job->W = width; job->H = height; job->aaX = aa_x; job->aaY = aa_y; job->maxDepth = max_depth;

@@ -175,3 +175,35 @@ def test_whole_frames_on_one_lane_equal_sharded_frames(c2, aa):
     for (a, an, ash), (b, bn, bsh) in zip(ref, got):
         assert (an, ash) == (bn, bsh)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_queues_grow_for_a_large_frame(c2, monkeypatch):
+    """A frame that brings more rays per lane than two batches of the present queues hold makes rt_render_submit grow them (8 Mi -> up to
+    32 Mi entries; RT_QUEUE_RAYS fixes the size): frames already in flight are finished first, and the large frame -- now a few large
+    batches per lane instead of many -- has the same pixels, bit for bit, and the same ray counts as with the fixed queues."""
+    flat, _ = c2
+    W, H, aa = 1920, 1080, 4                                               # 33 M primary rays, 8.3 M per lane
+    cam = rt.Camera(flat.fov, W, H, eye=(0.1, 1.5, 1.0), rot_x=-0.3)
+    small_cam = rt.Camera(flat.fov, 480, 270, eye=(0, 1.5, 1.0), rot_x=-0.3)
+    monkeypatch.setenv("RT_QUEUE_RAYS", str(8 << 20))
+    fixed = rt.Scene(flat, 0)
+    monkeypatch.delenv("RT_QUEUE_RAYS")
+    ref, ref_small = torch.zeros(H, W, 3, device="cuda"), torch.zeros(270, 480, 3, device="cuda")
+    st_ref = fixed.render_into(ref.data_ptr(), W, H, camera=cam, aa=aa)
+    fixed.render_into(ref_small.data_ptr(), 480, 270, camera=small_cam)
+    fixed.close()
+    sc = rt.Scene(flat, 0)
+    big, small = torch.zeros(H, W, 3, device="cuda"), torch.zeros(270, 480, 3, device="cuda")
+    ts = sc.render_submit(small.data_ptr(), 480, 270, camera=small_cam)   # in flight while the queues grow
+    tb = sc.render_submit(big.data_ptr(), W, H, camera=cam, aa=aa)
+    st_big = sc.render_wait(tb)
+    sc.render_wait(ts)
+    assert torch.equal(big, ref) and torch.equal(small, ref_small)
+    assert (st_big["rays_nearest"], st_big["rays_shadow"]) == (st_ref["rays_nearest"], st_ref["rays_shadow"])
+    assert st_big["rays_nearest"] == W * H * aa * aa
+    again = torch.zeros(H, W, 3, device="cuda")
+    sc.render_into(again.data_ptr(), W, H, camera=cam, aa=aa, flags=rt.RT_FLAG_WHOLE_FRAME)
+    small.zero_()
+    sc.render_into(small.data_ptr(), 480, 270, camera=small_cam)
+    assert torch.equal(again, ref) and torch.equal(small, ref_small)
+    sc.close()

@@ -736,7 +736,17 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			float4* buf = L.level(info);
 			if ((nidx & (RT_QUAD_SLOTS - 1)) == 0 && nidx != 0) {   // the root of a deeper treelet: stage it
 #pragma unroll
+#if RT_ABLATE & 2
+				// diagnostic builds only: every treelet fetched twice, the second fetch depending on the first (what do the fetches' round trips cost?)
+				for (uint32_t k = 0; k < RT_QUAD_SLOTS * 4u; k += 64u) {
+					const float4 once = S.quads[(size_t)nidx * 4 + k + lane];
+					uint32_t z = __float_as_uint(once.x);
+					asm volatile("v_and_b32 %0, 0, %0" : "+v"(z));
+					buf[k + lane] = S.quads[(size_t)nidx * 4 + k + lane + z];
+				}
+#else
 				for (uint32_t k = 0; k < RT_QUAD_SLOTS * 4u; k += 64u) buf[k + lane] = S.quads[(size_t)nidx * 4 + k + lane];
+#endif
 				__builtin_amdgcn_wave_barrier();
 				TR(4, nidx >> 4);
 			}

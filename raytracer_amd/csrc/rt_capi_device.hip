@@ -6,6 +6,7 @@
 #include "host/host_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -508,45 +509,126 @@ void buildMeshTrees(const rt_flat_scene* s, MeshTrees& M) {
 	if (M.depth > RT_MESH_STACK) { M.nodes.clear(); M.order.clear(); M.roots.assign(M.roots.size(), -1); }   // (a degenerate mesh: keep the scan)
 }
 
-// Cuts the augmented tree into treelets (layout in rt_kernels.h).  Returns the number of treelet levels.
-int buildTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std::vector<rt_bvh_node>& out, bool& externalRuns) {
+// ---------------------------------------------------------------------------------------------------------
+// Cutting a tree into treelets, on several threads.  A treelet is filled breadth first from its root until its slots are used up; the
+// nodes that no longer fit root treelets of their own, one level further down.  What a treelet holds depends on its root alone, so once
+// the top of the tree is cut and enough roots are waiting, the subtrees below them are cut independently -- each into treelets numbered
+// from 0, with the references between them local -- and then copied behind the top, their references moved by where they landed.  The
+// treelets come out grouped by subtree instead of level by level; every treelet's contents are what the sequential cut gives it.
+// ---------------------------------------------------------------------------------------------------------
+int g_cutThreads = 0;   // rt_debug_treelet_digest: the number of threads to cut with (0: by the size of the tree)
+struct CutRoot { int32_t node; int level; int depth; };
+struct Cut {
+	std::vector<rt_bvh_node> slots;   // treelets 0 .. roots.size() - 1 as far as they have been cut
+	std::vector<uint8_t> records;     // per cut treelet: the node records at its front (the rest of its slots are triangles)
+	std::vector<CutRoot> roots;       // roots[t]: what treelet t starts from; a reference to treelet t is t * slotsPerTreelet (| flags)
+	int levels = 0, depth = 0;
+	bool externalRuns = false;
+	std::string error;
+};
+// one(cut, t, scratch): cuts treelet t of `cut` (appends the roots it leaves, references them by their index in cut.roots); false = failed
+// reloc(record, f): replaces the index part i of every reference to a node record in `record` by f(i)
+template <class Scratch, class One, class Reloc>
+int cutTree(int32_t root, size_t slotsPerTreelet, size_t slotsPerRecord, size_t treeNodes, One one, Reloc reloc, rt::PodVec<rt_bvh_node>& out, bool& externalRuns, int& depth) {
 	out.clear();
-	externalRuns = false;
-	if (A.root < 0) return 0;
-	struct Root { int32_t node; int level; };
-	std::vector<Root> roots{ { A.root, 0 } };
-	int levels = 0;
+	externalRuns = false; depth = 0;
+	if (root < 0) return 0;
+	static const unsigned maxThreads = std::max(1u, std::min(envU32("RT_UPLOAD_THREADS", 16), std::max(1u, std::thread::hardware_concurrency())));
+	const unsigned threads = g_cutThreads > 0 ? (unsigned)g_cutThreads : treeNodes >= 20000 ? maxThreads : 1u;
+	Cut top;
+	top.roots.push_back({ root, 0, 1 });
+	top.slots.reserve(threads > 1 ? 4096 * slotsPerTreelet : (treeNodes / 2 + 64) * slotsPerTreelet);
+	Scratch scratch;
+	size_t t = 0;
+	for (; t < top.roots.size(); t++) {
+		if (threads > 1 && t >= 64 && top.roots.size() - t >= 16 * (size_t)threads) break;   // enough subtrees waiting: the rest in parallel
+		if (!one(top, t, scratch)) { rt::set_error(top.error); return -1; }
+	}
+	const size_t T0 = t, nJobs = top.roots.size() - T0;
+	std::vector<Cut> jobs(nJobs);
+	if (nJobs > 0) {
+		std::atomic<size_t> next{ 0 };
+		std::vector<std::thread> pool;
+		for (unsigned w = 0; w < threads; w++)
+			pool.emplace_back([&] {
+				Scratch mine;
+				for (size_t j; (j = next.fetch_add(1)) < nJobs;) {
+					Cut& C = jobs[j];
+					C.roots.push_back(top.roots[T0 + j]);
+					for (size_t lt = 0; lt < C.roots.size(); lt++)
+						if (!one(C, lt, mine)) { C.roots.clear(); break; }   // (error kept in C.error)
+				}
+			});
+		for (auto& th : pool) th.join();
+	}
+	std::vector<size_t> base(nJobs + 1, T0);
+	for (size_t j = 0; j < nJobs; j++) {
+		if (jobs[j].roots.empty()) { rt::set_error(jobs[j].error); return -1; }
+		base[j + 1] = base[j] + jobs[j].roots.size();
+	}
+	const size_t total = base[nJobs];
+	out.resize(total * slotsPerTreelet);
+	memcpy(out.data(), top.slots.data(), T0 * slotsPerTreelet * sizeof(rt_bvh_node));
+	// the top's references to the waiting roots: root T0 + j became treelet base[j]
+	for (size_t tt = 0; tt < T0; tt++)
+		for (size_t r = 0; r < top.records[tt]; r++)
+			reloc(&out[tt * slotsPerTreelet + r * slotsPerRecord], [&](size_t i) {
+				const size_t ti = i / slotsPerTreelet;
+				return ti >= T0 ? base[ti - T0] * slotsPerTreelet + i % slotsPerTreelet : i;
+			});
+	int levels = top.levels;
+	depth = top.depth; externalRuns = top.externalRuns;
+	if (nJobs > 0) {
+		std::atomic<size_t> next{ 0 };
+		std::vector<std::thread> pool;
+		for (unsigned w = 0; w < threads; w++)
+			pool.emplace_back([&] {
+				for (size_t j; (j = next.fetch_add(1)) < nJobs;) {
+					const Cut& C = jobs[j];
+					rt_bvh_node* dst = out.data() + base[j] * slotsPerTreelet;
+					memcpy(dst, C.slots.data(), C.roots.size() * slotsPerTreelet * sizeof(rt_bvh_node));
+					const size_t shift = base[j] * slotsPerTreelet;
+					for (size_t lt = 0; lt < C.roots.size(); lt++)
+						for (size_t r = 0; r < C.records[lt]; r++) reloc(dst + lt * slotsPerTreelet + r * slotsPerRecord, [&](size_t i) { return i + shift; });
+				}
+			});
+		for (auto& th : pool) th.join();
+		for (const Cut& C : jobs) { levels = std::max(levels, C.levels); depth = std::max(depth, C.depth); externalRuns |= C.externalRuns; }
+	}
+	return levels;
+}
+
+// Cuts the augmented tree into treelets (layout in rt_kernels.h).  Returns the number of treelet levels.
+int buildTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, rt::PodVec<rt_bvh_node>& out, bool& externalRuns) {
 	struct Member { int32_t node; bool embedLeaf[2]; };
-	std::vector<Member> member;
-	std::vector<int32_t> childSlot;   // per member, per child: slot of an in-treelet inner child, -1 otherwise
-	out.reserve((A.nodes.size() / 2 + 64) * RT_TREELET_SLOTS);   // (about what a tree of 4-triangle sub-leaves needs: no regrowth copies of a 0.6 GB array)
+	struct Scratch { std::vector<Member> member; std::vector<int32_t> childSlot; };   // childSlot: per member, per child: slot of an in-treelet inner child, -1 otherwise
 	// triangles a leaf brings into the treelet if it is embedded: sub-leaves always, reference runs up to RT_TREELET_EMBED_MAX
 	auto embeddable = [&](int32_t c) -> uint32_t {
 		const AugTree::Leaf& L = A.leaves[(size_t)~c];
 		if (L.sub) return L.count;
 		return (embed && L.count > 0 && L.count <= RT_TREELET_EMBED_MAX && L.first < RT_TREELET_EMBED) ? L.count : 0u;
 	};
-	for (size_t t = 0; t < roots.size(); t++) {
-		out.resize((t + 1) * RT_TREELET_SLOTS, rt_bvh_node{});
-		const int level = roots[t].level;
-		levels = std::max(levels, level + 1);
+	auto one = [&](Cut& C, size_t t, Scratch& X) -> bool {
+		std::vector<Member>& member = X.member;
+		std::vector<int32_t>& childSlot = X.childSlot;
+		C.slots.resize((t + 1) * RT_TREELET_SLOTS, rt_bvh_node{});
+		const int level = C.roots[t].level;
+		C.levels = std::max(C.levels, level + 1);
 		member.clear();
 		uint32_t used = 0;
 		auto join = [&](int32_t node, bool must) {
 			const AugTree::Node& b = A.nodes[(size_t)node];
 			uint32_t tris[2] = { 0, 0 };
-			bool sub = false;
-			for (int k = 0; k < 2; k++) if (b.child[k] < 0) { tris[k] = embeddable(b.child[k]); sub |= A.leaves[(size_t)~b.child[k]].sub; }
+			for (int k = 0; k < 2; k++) if (b.child[k] < 0) tris[k] = embeddable(b.child[k]);
 			if (!must && used + 1 + tris[0] + tris[1] > RT_TREELET_SLOTS) return false;
 			Member m{ node, { false, false } };
 			used += 1;
 			for (int k = 0; k < 2; k++)   // the root joins whatever it brings; its runs are embedded while they fit (sub-leaves always do)
 				if (tris[k] && used + tris[k] <= RT_TREELET_SLOTS) { m.embedLeaf[k] = true; used += tris[k]; }
-			(void)sub;
 			member.push_back(m);
 			return true;
 		};
-		join(roots[t].node, true);
+		join(C.roots[t].node, true);
 		childSlot.clear();
 		for (size_t i = 0; i < member.size(); i++) {
 			const AugTree::Node& b = A.nodes[(size_t)member[i].node];
@@ -556,10 +638,11 @@ int buildTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std::vec
 				childSlot.push_back(slot);
 			}
 		}
+		C.records.push_back((uint8_t)member.size());
 		uint32_t triSlot = (uint32_t)member.size();
 		for (size_t i = 0; i < member.size(); i++) {
 			const AugTree::Node& b = A.nodes[(size_t)member[i].node];
-			rt_bvh_node& o = out[t * RT_TREELET_SLOTS + i];
+			rt_bvh_node& o = C.slots[t * RT_TREELET_SLOTS + i];
 			memcpy(o.box, b.box, sizeof o.box);
 			for (int k = 0; k < 2; k++) {
 				const int32_t c = b.child[k];
@@ -573,26 +656,34 @@ int buildTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std::vec
 							rt_tri tri = s->tris[index];
 							tri.mesh = (int32_t)index;                                                             // -> T.best
 							tri.uv = (int32_t)(L.sub ? A.subKeys[L.first + j] : (uint32_t)~L.ref + j + 1u);      // -> tie-break key
-							memcpy(&out[t * RT_TREELET_SLOTS + triSlot], &tri, sizeof tri);
+							memcpy(&C.slots[t * RT_TREELET_SLOTS + triSlot], &tri, sizeof tri);
 						}
 					} else {
-						if (L.sub) { rt::set_error("internal: a sub-leaf did not fit its treelet"); return -1; }
+						if (L.sub) { C.error = "internal: a sub-leaf did not fit its treelet"; return false; }
 						o.count[k] = (int32_t)externalAux(TriRun{ L.first, L.count }, L.ref);
-						externalRuns |= (uint32_t)o.count[k] != RT_TREELET_NO_RUN;
+						C.externalRuns |= (uint32_t)o.count[k] != RT_TREELET_NO_RUN;
 					}
 				} else {
 					const uint32_t flag = A.nodes[(size_t)c].cons ? RT_TREELET_CONS : 0u;
 					if (childSlot[2 * i + k] >= 0) o.child[k] = (int32_t)((uint32_t)(t * RT_TREELET_SLOTS + childSlot[2 * i + k]) | flag);
 					else {
-						o.child[k] = (int32_t)((uint32_t)(roots.size() * RT_TREELET_SLOTS) | flag);
-						roots.push_back({ c, level + 1 });
+						o.child[k] = (int32_t)((uint32_t)(C.roots.size() * RT_TREELET_SLOTS) | flag);
+						C.roots.push_back({ c, level + 1, 0 });
 					}
 					o.count[k] = 0;
 				}
 			}
 		}
-	}
-	return levels;
+		return true;
+	};
+	auto reloc = [](rt_bvh_node* rec, auto&& f) {
+		for (int k = 0; k < 2; k++) {
+			const int32_t c = rec->child[k];
+			if (c >= 0) rec->child[k] = (int32_t)((uint32_t)f((size_t)((uint32_t)c & (RT_TREELET_CONS - 1u))) | ((uint32_t)c & RT_TREELET_CONS));
+		}
+	};
+	int depth = 0;
+	return cutTree<Scratch>(A.root, RT_TREELET_SLOTS, 1, A.nodes.size(), one, reloc, out, externalRuns, depth);
 }
 
 // The same tree as quad nodes for the packet walks (layout in rt_kernels.h, reasons in rt_kernels.hip "Quad nodes"): the node that
@@ -601,18 +692,14 @@ int buildTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std::vec
 // a fat leaf: the reference's exact verdict on the leaf's box must be kept).  A quad takes two 64 B slots of a treelet; the treelets
 // are cut as above (breadth first, a quad joins only if the triangles of its embeddable leaves fit as well).  Returns the number of
 // treelet levels, `quadDepth` = quads on the longest root-to-leaf path.
-int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std::vector<rt_bvh_node>& out, bool& externalRuns, int& quadDepth) {
-	out.clear();
-	externalRuns = false;
-	quadDepth = 0;
-	if (A.root < 0) return 0;
+int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, rt::PodVec<rt_bvh_node>& out, bool& externalRuns, int& quadDepth) {
 	struct Entry { float box[6]; int32_t ref; };   // ref >= 0: binary node whose quad this entry leads to; < 0: ~index into A.leaves
+	static const uint32_t collapse = envU32("RT_QUAD_COLLAPSE", 3);   // diagnostic: bit 0 reference nodes, bit 1 sub-tree nodes
 	auto entriesOf = [&](int32_t n, Entry* e, bool skipLevel) -> int {
 		const AugTree::Node& b = A.nodes[(size_t)n];
 		int count = 0;
 		for (int k = 0; k < 2; k++) {
 			const int32_t c = b.child[k];
-			static const uint32_t collapse = envU32("RT_QUAD_COLLAPSE", 3);   // diagnostic: bit 0 reference nodes, bit 1 sub-tree nodes
 			if (skipLevel && c >= 0 && A.nodes[(size_t)c].cons == b.cons && (collapse & (b.cons ? 2u : 1u))) {   // same regime: the child's own box is skipped
 				const AugTree::Node& m = A.nodes[(size_t)c];
 				for (int j = 0; j < 2; j++) { memcpy(e[count].box, m.box[j], sizeof e[count].box); e[count].ref = m.child[j]; count++; }
@@ -620,21 +707,18 @@ int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std:
 		}
 		return count;
 	};
-	struct Root { int32_t node; int level; int depth; };
-	std::vector<Root> roots{ { A.root, 0, 1 } };
-	int levels = 0;
 	struct Member { int32_t node; int depth; Entry e[4]; int n; bool embedLeaf[4]; int32_t childSlot[4]; };
-	std::vector<Member> member;
-	out.reserve((A.nodes.size() / 2 + 64) * RT_QUAD_SLOTS);
+	struct Scratch { std::vector<Member> member; };
 	auto embeddable = [&](int32_t c) -> uint32_t {
 		const AugTree::Leaf& L = A.leaves[(size_t)~c];
 		if (L.sub) return L.count;
 		return (embed && L.count > 0 && L.count <= RT_TREELET_EMBED_MAX && L.first < RT_TREELET_EMBED) ? L.count : 0u;
 	};
-	for (size_t t = 0; t < roots.size(); t++) {
-		out.resize((t + 1) * RT_QUAD_SLOTS, rt_bvh_node{});
-		const int level = roots[t].level;
-		levels = std::max(levels, level + 1);
+	auto one = [&](Cut& C, size_t t, Scratch& X) -> bool {
+		std::vector<Member>& member = X.member;
+		C.slots.resize((t + 1) * RT_QUAD_SLOTS, rt_bvh_node{});
+		const int level = C.roots[t].level;
+		C.levels = std::max(C.levels, level + 1);
 		member.clear();
 		uint32_t used = 0;
 		auto join = [&](int32_t node, int depth, bool must) {
@@ -657,21 +741,22 @@ int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std:
 				m.embedLeaf[i] = tris[i] && used + tris[i] <= RT_QUAD_SLOTS;   // (the root joins whatever it brings; its runs are embedded while they fit)
 				if (m.embedLeaf[i]) used += tris[i];
 			}
-			quadDepth = std::max(quadDepth, depth);
+			C.depth = std::max(C.depth, depth);
 			member.push_back(m);
 			return true;
 		};
-		join(roots[t].node, roots[t].depth, true);
+		join(C.roots[t].node, C.roots[t].depth, true);
 		for (size_t i = 0; i < member.size(); i++)
 			for (int k = 0; k < member[i].n; k++) {
 				const int32_t ref = member[i].e[k].ref;
 				const int depth = member[i].depth + 1;
 				if (ref >= 0 && join(ref, depth, false)) member[i].childSlot[k] = 2 * ((int32_t)member.size() - 1);
 			}
+		C.records.push_back((uint8_t)member.size());
 		uint32_t triSlot = 2u * (uint32_t)member.size();
 		for (size_t i = 0; i < member.size(); i++) {
 			const Member& m = member[i];
-			float* rec = reinterpret_cast<float*>(&out[t * RT_QUAD_SLOTS + 2 * i]);   // 32 floats: 4 boxes, 4 children, 4 aux words
+			float* rec = reinterpret_cast<float*>(&C.slots[t * RT_QUAD_SLOTS + 2 * i]);   // 32 floats: 4 boxes, 4 children, 4 aux words
 			int32_t* child = reinterpret_cast<int32_t*>(rec + 24);
 			uint32_t* aux = reinterpret_cast<uint32_t*>(rec + 28);
 			for (int k = 0; k < 4; k++) {
@@ -692,26 +777,34 @@ int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, std:
 							rt_tri tri = s->tris[index];
 							tri.mesh = (int32_t)index;                                                             // -> T.best
 							tri.uv = (int32_t)(L.sub ? A.subKeys[L.first + j] : (uint32_t)~L.ref + j + 1u);      // -> tie-break key
-							memcpy(&out[t * RT_QUAD_SLOTS + triSlot], &tri, sizeof tri);
+							memcpy(&C.slots[t * RT_QUAD_SLOTS + triSlot], &tri, sizeof tri);
 						}
 					} else {
-						if (L.sub) { rt::set_error("internal: a sub-leaf did not fit its treelet"); return -1; }
+						if (L.sub) { C.error = "internal: a sub-leaf did not fit its treelet"; return false; }
 						aux[k] = externalAux(TriRun{ L.first, L.count }, L.ref);
-						externalRuns |= aux[k] != RT_TREELET_NO_RUN;
+						C.externalRuns |= aux[k] != RT_TREELET_NO_RUN;
 					}
 				} else {
 					const uint32_t flag = A.nodes[(size_t)c].cons ? RT_TREELET_CONS : 0u;
 					if (m.childSlot[k] >= 0) { child[k] = (int32_t)((uint32_t)(t * RT_QUAD_SLOTS + (size_t)m.childSlot[k]) | flag); aux[k] = 0; }
 					else {   // roots another treelet, one level further down (aux = what the walk adds to the level)
-						child[k] = (int32_t)((uint32_t)(roots.size() * RT_QUAD_SLOTS) | flag);
-						roots.push_back({ c, level + 1, m.depth + 1 });
+						child[k] = (int32_t)((uint32_t)(C.roots.size() * RT_QUAD_SLOTS) | flag);
+						C.roots.push_back({ c, level + 1, m.depth + 1 });
 						aux[k] = 1;
 					}
 				}
 			}
 		}
-	}
-	return levels;
+		return true;
+	};
+	auto reloc = [](rt_bvh_node* rec, auto&& f) {
+		int32_t* child = reinterpret_cast<int32_t*>(reinterpret_cast<float*>(rec) + 24);
+		for (int k = 0; k < 4; k++) {
+			const int32_t c = child[k];
+			if (c >= 0 && c != RT_QUAD_EMPTY) child[k] = (int32_t)((uint32_t)f((size_t)((uint32_t)c & (RT_TREELET_CONS - 1u))) | ((uint32_t)c & RT_TREELET_CONS));
+		}
+	};
+	return cutTree<Scratch>(A.root, RT_QUAD_SLOTS, 2, A.nodes.size(), one, reloc, out, externalRuns, quadDepth);
 }
 
 // Where a call's rays come from and where first-level results go.
@@ -1136,6 +1229,85 @@ struct DevBuf {   // scoped device allocation
 
 extern "C" {
 
+// Test hook (tests/test_treelet_cut.py; no device needed): both treelet forms of a scene cut with `threads` threads (1 = the sequential
+// cut), each reduced to a digest of the tree as a walk from the root sees it -- every record's boxes and aux words, every embedded
+// triangle, every leaf reference, and where each reference to another record leads (its slot within the treelet and the record behind
+// it) but not the treelets' numbers, which is all a parallel cut may change.  out[0..1] digests, out[2..3] treelets of the two forms.
+int rt_debug_treelet_digest(const rt_flat_scene* s, int threads, uint64_t out[4]) {
+	if (!s || !out || threads < 1) { rt::set_error("rt_debug_treelet_digest: bad argument"); return RT_EINVAL; }
+	if (int rc = rt::validate_flat_scene(s)) return rc;
+	AugTree aug;
+	buildAugTree(s, true, aug);
+	rt::PodVec<rt_bvh_node> binary, quads;
+	bool runsB = false, runsQ = false;
+	int quadDepth = 0;
+	g_cutThreads = threads;
+	const int lb = buildTreelets(s, aug, true, binary, runsB);
+	const int lq = buildQuadTreelets(s, aug, true, quads, runsQ, quadDepth);
+	g_cutThreads = 0;
+	if (lb < 0 || lq < 0) return RT_EINVAL;
+	auto mix = [](uint64_t& h, uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); h *= 0xff51afd7ed558ccdull; h ^= h >> 33; };
+	auto mixBytes = [&](uint64_t& h, const void* p, size_t n) { const uint32_t* w = static_cast<const uint32_t*>(p); for (size_t i = 0; i < n / 4; i++) mix(h, w[i]); };
+	bool bad = false;
+	// binary form: a record = rt_bvh_node (two boxes, child[2], count[2])
+	uint64_t hB = (uint64_t)lb << 1 | (runsB ? 1u : 0u);
+	if (!binary.empty()) {
+		std::vector<size_t> st{ 0 };
+		while (!st.empty()) {
+			const size_t at = st.back(); st.pop_back();
+			if (at >= binary.size()) { bad = true; break; }
+			const rt_bvh_node& n = binary[at];
+			mixBytes(hB, n.box, sizeof n.box);
+			for (int k = 1; k >= 0; k--) {
+				const int32_t c = n.child[k];
+				mix(hB, (uint32_t)n.count[k] & ~(RT_TREELET_SLOTS - 1u));   // (an embedded run's slot is hashed below, through its triangles)
+				if (c >= 0) { const size_t i = (uint32_t)c & (RT_TREELET_CONS - 1u); mix(hB, (i % RT_TREELET_SLOTS) << 1 | (((uint32_t)c & RT_TREELET_CONS) ? 1u : 0u)); st.push_back(i); }
+				else {
+					mix(hB, (uint32_t)c);
+					const uint32_t aux = (uint32_t)n.count[k];
+					if (aux != RT_TREELET_NO_RUN && (aux >> 26) != 0 && (aux & RT_TREELET_EMBED)) {
+						const size_t first = at / RT_TREELET_SLOTS * RT_TREELET_SLOTS + (aux & (RT_TREELET_SLOTS - 1u));
+						if (first + (aux >> 26) > binary.size()) { bad = true; break; }
+						mix(hB, aux & (RT_TREELET_SLOTS - 1u));
+						mixBytes(hB, &binary[first], (aux >> 26) * sizeof(rt_bvh_node));
+					}
+				}
+			}
+			if (bad) break;
+		}
+	}
+	// quad form: a record = 32 floats (four boxes, four children, four aux words) in two slots
+	uint64_t hQ = (uint64_t)lq << 9 | (uint64_t)quadDepth << 1 | (runsQ ? 1u : 0u);
+	if (!quads.empty() && !bad) {
+		std::vector<size_t> st{ 0 };
+		while (!st.empty()) {
+			const size_t at = st.back(); st.pop_back();
+			if (at + 1 >= quads.size()) { bad = true; break; }
+			const float* rec = reinterpret_cast<const float*>(&quads[at]);
+			const int32_t* child = reinterpret_cast<const int32_t*>(rec + 24);
+			const uint32_t* aux = reinterpret_cast<const uint32_t*>(rec + 28);
+			mixBytes(hQ, rec, 24 * sizeof(float));
+			for (int k = 3; k >= 0; k--) {
+				const int32_t c = child[k];
+				if (c == RT_QUAD_EMPTY) { mix(hQ, 0x7fffffffu); continue; }
+				if (c >= 0) { const size_t i = (uint32_t)c & (RT_TREELET_CONS - 1u); mix(hQ, (i % RT_QUAD_SLOTS) << 2 | (((uint32_t)c & RT_TREELET_CONS) ? 2u : 0u) | (aux[k] & 1u)); st.push_back(i); }
+				else {
+					mix(hQ, (uint32_t)c); mix(hQ, aux[k]);
+					if (aux[k] != RT_TREELET_NO_RUN && (aux[k] >> 26) != 0 && (aux[k] & RT_TREELET_EMBED)) {
+						const size_t first = at / RT_QUAD_SLOTS * RT_QUAD_SLOTS + (aux[k] & (RT_QUAD_SLOTS - 1u));
+						if (first + (aux[k] >> 26) > quads.size()) { bad = true; break; }
+						mixBytes(hQ, &quads[first], (aux[k] >> 26) * sizeof(rt_bvh_node));
+					}
+				}
+			}
+			if (bad) break;
+		}
+	}
+	if (bad) { rt::set_error("rt_debug_treelet_digest: a reference leads outside the treelets"); return RT_EINVAL; }
+	out[0] = hB; out[1] = hQ; out[2] = binary.size() / RT_TREELET_SLOTS; out[3] = quads.size() / RT_QUAD_SLOTS;
+	return RT_OK;
+}
+
 int rt_device_count(void) {
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1192,7 +1364,7 @@ int rt_scene_upload(const rt_flat_scene* s, int device, rt_scene** out) {
 	}
 	{
 		static_assert(sizeof(rt_tri) == sizeof(rt_bvh_node) && sizeof(rt_bvh_node) == 64, "treelet slots are 64 B");
-		std::vector<rt_bvh_node> treelets, quads;
+		rt::PodVec<rt_bvh_node> treelets, quads;
 		bool externalRuns = false, quadRuns = false;
 		int quadDepth = 0;
 		AugTree aug;

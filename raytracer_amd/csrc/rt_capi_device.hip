@@ -786,11 +786,12 @@ int buildQuadTreelets(const rt_flat_scene* s, const AugTree& A, bool embed, rt::
 					}
 				} else {
 					const uint32_t flag = A.nodes[(size_t)c].cons ? RT_TREELET_CONS : 0u;
-					if (m.childSlot[k] >= 0) { child[k] = (int32_t)((uint32_t)(t * RT_QUAD_SLOTS + (size_t)m.childSlot[k]) | flag); aux[k] = 0; }
-					else {   // roots another treelet, one level further down (aux = what the walk adds to the level)
+					// (aux of an inner entry = the treelet level of the quad it leads to: which of the wave's LDS buffers holds, or will hold, that treelet)
+					if (m.childSlot[k] >= 0) { child[k] = (int32_t)((uint32_t)(t * RT_QUAD_SLOTS + (size_t)m.childSlot[k]) | flag); aux[k] = (uint32_t)level; }
+					else {   // roots another treelet, one level further down
 						child[k] = (int32_t)((uint32_t)(C.roots.size() * RT_QUAD_SLOTS) | flag);
 						C.roots.push_back({ c, level + 1, m.depth + 1 });
-						aux[k] = 1;
+						aux[k] = (uint32_t)level + 1u;
 					}
 				}
 			}
@@ -1290,7 +1291,7 @@ int rt_debug_treelet_digest(const rt_flat_scene* s, int threads, uint64_t out[4]
 			for (int k = 3; k >= 0; k--) {
 				const int32_t c = child[k];
 				if (c == RT_QUAD_EMPTY) { mix(hQ, 0x7fffffffu); continue; }
-				if (c >= 0) { const size_t i = (uint32_t)c & (RT_TREELET_CONS - 1u); mix(hQ, (i % RT_QUAD_SLOTS) << 2 | (((uint32_t)c & RT_TREELET_CONS) ? 2u : 0u) | (aux[k] & 1u)); st.push_back(i); }
+				if (c >= 0) { const size_t i = (uint32_t)c & (RT_TREELET_CONS - 1u); mix(hQ, (i % RT_QUAD_SLOTS) << 1 | (((uint32_t)c & RT_TREELET_CONS) ? 1u : 0u)); mix(hQ, aux[k]); st.push_back(i); }
 				else {
 					mix(hQ, (uint32_t)c); mix(hQ, aux[k]);
 					if (aux[k] != RT_TREELET_NO_RUN && (aux[k] >> 26) != 0 && (aux[k] & RT_TREELET_EMBED)) {

@@ -54,8 +54,8 @@
 #define RT_TREELET_SUBLEAF_MAX 4u         /* triangles per leaf of such a sub-tree */
 #define RT_TREELET_CONS (1u << 29)        /* flag on a child reference: the node belongs to a sub-tree, its box tests are conservative */
 // Quad nodes (the packet walks' form of the tree, DevScene::quads): 128 B = two consecutive slots (the first one even) of such a
-// treelet: float box[4][6], int32 child[4], uint32 aux[4] -- child and aux as above (aux of an inner entry: 1 if it roots another
-// treelet, else 0), RT_QUAD_EMPTY for an entry that does not exist
+// treelet: float box[4][6], int32 child[4], uint32 aux[4] -- child and aux as above (aux of an inner entry: the treelet level of
+// the quad it leads to, i.e. which per-level LDS buffer of the wave holds that treelet), RT_QUAD_EMPTY for an entry that does not exist
 // (its box is inverted: nothing passes it).  RT_TREELET_CONS on the reference to a quad: its four boxes are conservative.
 #define RT_QUAD_EMPTY 0x7fffffff
 #ifndef RT_QUAD_SLOTS

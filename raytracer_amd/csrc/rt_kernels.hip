@@ -793,9 +793,11 @@ __device__ __forceinline__ void packetTraverse(const DevScene& S, const PacketLd
 			// rays: any order is correct).  The other entries that some ray passed wait on the stack.  Written out per case: the entry's
 			// words are in scalar registers, and picking them by a run-time index costs more instructions than the step's box tests.
 			// (sp < RT_PACKET_STACK_DEPTH always holds: rt_scene_upload refuses a tree that does not pass RT_PACKET_STACK_FITS, rt_kernels.h)
-#define RT_Q_INF(i) (Q.c[i] < 0 ? Q.x[i] : info + Q.x[i])   /* inner entry: aux = 1 if it roots another treelet (one level further down) */
-#define RT_Q_PUSH(i) do { if (m[i] != 0 && sp < RT_PACKET_STACK_DEPTH) { *reinterpret_cast<uint4*>(L.stack[sp]) = make_uint4((uint32_t)Q.c[i], (uint32_t)m[i], (uint32_t)(m[i] >> 32), RT_Q_INF(i)); sp++; } } while (0)
-#define RT_Q_TAKE(i) do { const uint32_t inf_ = RT_Q_INF(i); node = Q.c[i]; info = inf_; in = m[i]; popNext = false; } while (0)
+			// (sp <= RT_PACKET_STACK_DEPTH - 3 holds here, see above; one clamp per step keeps a broken invariant inside the stack's memory)
+			sp = sp > RT_PACKET_STACK_DEPTH - 3 ? RT_PACKET_STACK_DEPTH - 3 : sp;
+#define RT_Q_INF(i) Q.x[i]   /* leaf: its aux word; inner entry: the treelet level of its quad */
+#define RT_Q_PUSH(i) do { if (m[i] != 0) { *reinterpret_cast<uint4*>(L.stack[sp]) = make_uint4((uint32_t)Q.c[i], (uint32_t)m[i], (uint32_t)(m[i] >> 32), RT_Q_INF(i)); sp++; } } while (0)
+#define RT_Q_TAKE(i) do { node = Q.c[i]; info = RT_Q_INF(i); in = m[i]; popNext = false; } while (0)
 			uint32_t first;
 			if (!ANYHIT) {
 				const uint32_t k01 = key[0] < key[1] ? key[0] : key[1], k23 = key[2] < key[3] ? key[2] : key[3];
@@ -947,10 +949,11 @@ __device__ __forceinline__ void packetTraverse2(const DevScene& S, const PacketL
 			}
 			// the first entry any ray passed is walked next, the others wait on the stack (any order is correct for shadow rays); written
 			// out per case, see packetTraverse
-#define RT_Q_INF(i) (Q.c[i] < 0 ? Q.x[i] : info + Q.x[i])
-#define RT_Q_PUSH(i) do { if ((mA[i] | mB[i]) != 0 && sp < RT_PACKET_STACK_DEPTH) { stack[2 * sp] = make_uint4((uint32_t)Q.c[i], RT_Q_INF(i), 0u, 0u); \
+			sp = sp > RT_PACKET_STACK_DEPTH - 3 ? RT_PACKET_STACK_DEPTH - 3 : sp;   // (never: see packetTraverse)
+#define RT_Q_INF(i) Q.x[i]
+#define RT_Q_PUSH(i) do { if ((mA[i] | mB[i]) != 0) { stack[2 * sp] = make_uint4((uint32_t)Q.c[i], RT_Q_INF(i), 0u, 0u); \
 				stack[2 * sp + 1] = make_uint4((uint32_t)mA[i], (uint32_t)(mA[i] >> 32), (uint32_t)mB[i], (uint32_t)(mB[i] >> 32)); sp++; } } while (0)
-#define RT_Q_TAKE(i) do { const uint32_t inf_ = RT_Q_INF(i); node = Q.c[i]; info = inf_; inA = mA[i]; inB = mB[i]; popNext = false; } while (0)
+#define RT_Q_TAKE(i) do { node = Q.c[i]; info = RT_Q_INF(i); inA = mA[i]; inB = mB[i]; popNext = false; } while (0)
 			if ((mA[0] | mB[0]) != 0) { RT_Q_PUSH(3); RT_Q_PUSH(2); RT_Q_PUSH(1); RT_Q_TAKE(0); }
 			else if ((mA[1] | mB[1]) != 0) { RT_Q_PUSH(3); RT_Q_PUSH(2); RT_Q_TAKE(1); }
 			else if ((mA[2] | mB[2]) != 0) { RT_Q_PUSH(3); RT_Q_TAKE(2); }

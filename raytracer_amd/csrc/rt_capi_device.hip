@@ -189,7 +189,7 @@ struct rt_scene {
 	}
 	// Larger queues for every lane (a frame whose share per lane does not fit the present ones in a batch or two: see rt_render_submit).
 	// The lanes must be idle and the GPU through with their work (drainLocked): the old buffers are released here.
-	int growQueues(uint32_t cap) {
+	int freeLaneQueues() {
 		for (Lane& ln : lanes)
 			for (RtQueue* q : { &ln.ray[0], &ln.ray[1], &ln.hitq, &ln.surfq, &ln.transq })
 				if (q->f) {
@@ -197,9 +197,22 @@ struct rt_scene {
 					HIPCHK(hipFree(q->f));
 					*q = RtQueue{};
 				}
-		qcap = cap;
-		for (Lane& ln : lanes) if (int rc = allocLaneQueues(ln)) return rc;
 		return RT_OK;
+	}
+	// (if the device cannot give that much -- other handles, other processes -- the size is halved until it can: at worst the old size,
+	// whose memory was just released, and the frame runs in more batches)
+	int growQueues(uint32_t cap) {
+		const uint32_t old = qcap;
+		for (;;) {
+			if (int rc = freeLaneQueues()) return rc;
+			qcap = cap;
+			int rc = RT_OK;
+			for (Lane& ln : lanes) if ((rc = allocLaneQueues(ln))) break;
+			if (rc == RT_OK) return RT_OK;
+			(void)hipGetLastError();
+			if (cap <= old) return rc;   // not even the size it had
+			cap = std::max(old, cap / 2);
+		}
 	}
 	int initLane(Lane& ln, bool ownStream) {
 		if (int rc = allocLaneQueues(ln)) return rc;

@@ -207,3 +207,32 @@ def test_queues_grow_for_a_large_frame(c2, monkeypatch):
     sc.render_into(small.data_ptr(), 480, 270, camera=small_cam)
     assert torch.equal(again, ref) and torch.equal(small, ref_small)
     sc.close()
+
+
+def test_queue_growth_falls_back_when_device_memory_is_short(c2):
+    """The device cannot give the larger queues (here: a tensor holds all but 3 GB of its memory): the growth is halved down to the size the
+    queues had, whose memory was just released, and the large frame is rendered in more batches -- same pixels, same counts."""
+    flat, _ = c2
+    W, H, aa = 1920, 1080, 4
+    cam = rt.Camera(flat.fov, W, H, eye=(0.1, 1.5, 1.0), rot_x=-0.3)
+    sc = rt.Scene(flat, 0)
+    ref, out = torch.zeros(H, W, 3, device="cuda"), torch.zeros(H, W, 3, device="cuda")
+    small = torch.zeros(270, 480, 3, device="cuda")
+    sc.render_into(small.data_ptr(), 480, 270, camera=rt.Camera(flat.fov, 480, 270, eye=(0, 1.5, 1.0), rot_x=-0.3))   # (accumulators, module load)
+    torch.cuda.synchronize()
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(int(free - 3 * 2 ** 30), dtype=torch.uint8, device="cuda")
+    try:
+        st = sc.render_into(out.data_ptr(), W, H, camera=cam, aa=aa)       # wants 16 Mi-entry queues: 12 GB where 6 + 3 are to be had
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    before, _ = torch.cuda.mem_get_info()
+    st_ref = sc.render_into(ref.data_ptr(), W, H, camera=cam, aa=aa)       # (now they grow: 6 -> 12 GB)
+    torch.cuda.synchronize()
+    after, _ = torch.cuda.mem_get_info()
+    assert before - after > 4 * 2 ** 30                                    # ... so they had not grown under the hog
+    assert torch.equal(out, ref)
+    assert (st["rays_nearest"], st["rays_shadow"]) == (st_ref["rays_nearest"], st_ref["rays_shadow"]) and st["rays_nearest"] == W * H * aa * aa
+    sc.close()

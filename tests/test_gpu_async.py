@@ -221,7 +221,11 @@ def test_queue_growth_falls_back_when_device_memory_is_short(c2):
     sc.render_into(small.data_ptr(), 480, 270, camera=rt.Camera(flat.fov, 480, 270, eye=(0, 1.5, 1.0), rot_x=-0.3))   # (accumulators, module load)
     torch.cuda.synchronize()
     free, _ = torch.cuda.mem_get_info()
-    hog = torch.empty(int(free - 3 * 2 ** 30), dtype=torch.uint8, device="cuda")
+    try:
+        hog = torch.empty(int(free - 3 * 2 ** 30), dtype=torch.uint8, device="cuda")
+    except RuntimeError:                                                   # (someone else on the card, or a fragmented pool: nothing to test with)
+        sc.close()
+        pytest.skip("cannot take the device's free memory in one piece")
     try:
         st = sc.render_into(out.data_ptr(), W, H, camera=cam, aa=aa)       # wants 16 Mi-entry queues: 12 GB where 6 + 3 are to be had
     finally:
